@@ -1,0 +1,185 @@
+/*
+ * volrend_hip.h -- C ABI of the MI355X (gfx950) PlenOctree ray-march library
+ * (libvolrend_hip.so).  Plain C: opaque handles, PODs, int error codes.
+ *
+ * This is the drop-in boundary for ONE path of sxyu/volrend: everything that
+ * the reference does on the CUDA device for `volrend_headless`.  Each entry
+ * point names the reference interface it replaces (paths relative to the
+ * reference tree):
+ *
+ *   vr_tree_upload / vr_tree_free   N3Tree::load_cuda / free_cuda      src/cuda/n3tree.cu:9-49
+ *   VrTreeDesc                      internal::TreeSpec                 include/volrend/internal/data_spec.hpp:23-50
+ *   VrCamera                        internal::CameraSpec + the 48-byte
+ *                                   Camera::_update upload             data_spec.hpp:11-22, src/camera.cpp:67-75
+ *   VrRenderOptions                 volrend::RenderOptions             include/volrend/render_options.hpp:11-53
+ *   vr_render                       volrend::launch_renderer +
+ *                                   device::render_kernel              include/volrend/cuda/renderer_kernel.hpp:9-12,
+ *                                                                      src/cuda/volrend.cu:78-173,195-245
+ *   vr_probe_coeffs                 retrieve_cursor_lumisphere_kernel  src/cuda/volrend.cu:175-191
+ *   vr_read_back                    cudaMemcpy2DFromArrayAsync         main_headless.cpp:217-219
+ *   vr_last_error / return codes    cuda_assert (print+exit) becomes
+ *                                   an error code, the library never
+ *                                   exits the process                  src/cuda/common.cu:8-21
+ *
+ * Asynchrony matches the reference: vr_render only enqueues on `stream`
+ * (a hipStream_t passed as void*, NULL = the null stream) and returns.
+ * The library owns device copies of trees; callers own output buffers,
+ * streams and events.  One host thread per device, or one thread driving
+ * several devices with explicit vr_set_device().
+ */
+#ifndef VOLREND_HIP_H_
+#define VOLREND_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VR_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------ */
+enum {
+    VR_OK = 0,
+    VR_ERR_INVALID_ARGUMENT = 1,
+    VR_ERR_HIP = 2,          /* a HIP runtime call failed; see vr_last_error() */
+    VR_ERR_NO_DEVICE = 3,
+    VR_ERR_BAD_TREE = 4,     /* child links out of range / cyclic / too deep */
+    VR_ERR_UNSUPPORTED = 5,
+    VR_ERR_OUT_OF_MEMORY = 6
+};
+
+/* DataFormat::format, include/volrend/data_format.hpp:9-15 */
+enum { VR_FORMAT_RGBA = 0, VR_FORMAT_SH = 1, VR_FORMAT_SG = 2, VR_FORMAT_ASG = 3 };
+
+/* Floating-point evaluation model of the kernel (DESIGN.md "FP contract").
+ * STRICT evaluates the reference source with one rounding per operator and is
+ * what the parity pin (host build of the reference) verifies bit for bit;
+ * FMA fuses a*b+c the way an nvcc -fmad=true build plausibly does. */
+enum { VR_FP_STRICT = 0, VR_FP_FMA = 1 };
+
+#define VR_MAX_BASIS 25 /* VOLREND_GLOBAL_BASIS_MAX, render_options.hpp:6 */
+
+typedef struct VrTreeOpaque* vr_tree_t;
+
+/* Host (or device, see `memory`) view of a loaded tree.npz -- the arguments of
+ * N3Tree::load_cuda.  child/data use the reference's flat layout:
+ *   child[capacity * N^3]            int32, relative node offsets, 0 = leaf
+ *   data [capacity * N^3 * data_dim] IEEE fp16, record = [R..,G..,B.., sigma] */
+typedef struct VrTreeDesc {
+    const int32_t* child;
+    const uint16_t* data;
+    const float* extra;      /* SG: basis_dim*4, ASG: basis_dim*11 floats; else NULL */
+    uint64_t extra_count;    /* number of floats in `extra` */
+    float offset[3];
+    float scale[3];
+    int32_t N;               /* branching factor per axis */
+    int64_t capacity;        /* nodes */
+    int32_t data_dim;
+    int32_t format;          /* VR_FORMAT_* */
+    int32_t basis_dim;       /* -1 for RGBA */
+    float ndc_width;         /* <= 0 disables the LLFF NDC warp (data_spec.hpp:47) */
+    float ndc_height;
+    float ndc_focal;
+    int32_t memory;          /* 0: pointers are host memory, 1: device memory */
+} VrTreeDesc;
+
+typedef struct VrTreeInfo {
+    int64_t capacity;
+    int32_t N, data_dim, format, basis_dim;
+    int32_t max_depth;       /* deepest leaf: child words read = max_depth + 1 */
+    int32_t device;
+    uint64_t device_bytes;   /* total HBM held for this tree */
+    uint64_t leaf_stride;    /* bytes between SH records in the device layout */
+} VrTreeInfo;
+
+/* CameraSpec: column-major 4x3 camera-to-world (right, up, back, centre) */
+typedef struct VrCamera {
+    float transform[12];
+    int32_t width, height;
+    float fx, fy;
+} VrCamera;
+
+/* Field for field volrend::RenderOptions (bools widened to int32). */
+typedef struct VrRenderOptions {
+    float step_size;
+    float sigma_thresh;
+    float stop_thresh;
+    float background_brightness;
+    float render_bbox[6];
+    int32_t basis_minmax[2];
+    float rot_dirs[3];
+    int32_t show_grid;
+    int32_t grid_max_depth;
+    int32_t render_depth;
+    int32_t enable_probe;
+    float probe[3];
+    int32_t probe_disp_size;
+} VrRenderOptions;
+
+/* Which pixels one call renders and where they land.
+ * The frame is cut into tile_w x tile_h tiles (row-major tile order; both
+ * multiples of 8, or 0/0 for "whole frame is one tile"); this call renders the
+ * tiles t with t % world == rank -- the multi-GPU screen-tile shard.
+ *   VR_LAYOUT_FRAME  : pixels go to their frame position, rgba + y*pitch + 4*x
+ *   VR_LAYOUT_COMPACT: the rank's k-th tile (k = t / world) is stored densely at
+ *                      rgba + k*tile_w*tile_h*4, row pitch tile_w*4 (the buffer
+ *                      a gather collective sends); use vr_assemble_tiles on the
+ *                      gathered buffer. */
+enum { VR_LAYOUT_FRAME = 0, VR_LAYOUT_COMPACT = 1 };
+
+typedef struct VrFrame {
+    void* rgba;             /* device RGBA8 (byte order R,G,B,A; A = 255) */
+    int64_t pitch;          /* bytes per row (FRAME layout); 0 = width*4 */
+    const float* depth;     /* device R32F W*H mesh depth, or NULL */
+    float* accum;           /* optional device float4 per frame pixel: trace_ray's
+                               out[] before the background composite; or NULL */
+    int32_t offscreen;      /* 1: composite over background_brightness (headless)
+                               0: composite over the RGBA8 already in `rgba` */
+    int32_t layout;         /* VR_LAYOUT_* */
+    int32_t tile_w, tile_h;
+    int32_t rank, world;    /* world <= 1: render everything */
+    int32_t fp_mode;        /* VR_FP_* */
+    int32_t reserved;
+} VrFrame;
+
+/* ---- library / device ------------------------------------------------- */
+int vr_abi_version(void);
+/* Thread-local description of the most recent failure on this thread. */
+const char* vr_last_error(void);
+int vr_device_count(int* count);
+/* Select the device for subsequent calls on this thread (cudaSetDevice,
+ * main_headless.cpp:108-111).  device < 0 keeps the current device. */
+int vr_set_device(int device);
+/* Fills name (<= name_len bytes) with the gcnArchName, e.g. "gfx950:..." */
+int vr_device_name(int device, char* name, size_t name_len);
+
+/* ---- tree ------------------------------------------------------------- */
+void vr_default_tree_desc(VrTreeDesc* desc);
+int vr_tree_upload(const VrTreeDesc* desc, vr_tree_t* out);
+int vr_tree_free(vr_tree_t tree);
+int vr_tree_info(vr_tree_t tree, VrTreeInfo* info);
+
+/* ---- render ----------------------------------------------------------- */
+void vr_default_options(VrRenderOptions* opt);
+void vr_default_frame(VrFrame* frame);
+/* Number of bytes of the COMPACT buffer of one rank for the given sharding. */
+int64_t vr_compact_bytes(int width, int height, int tile_w, int tile_h, int world);
+int vr_render(vr_tree_t tree, const VrCamera* cam, const VrRenderOptions* opt,
+              const VrFrame* frame, void* stream);
+/* gathered = world consecutive COMPACT buffers (rank-major), all device memory
+ * on the current device.  Writes the W x H frame. */
+int vr_assemble_tiles(void* frame_rgba, int64_t pitch, const void* gathered, int width,
+                      int height, int tile_w, int tile_h, int world, void* stream);
+/* out_dev: device float[data_dim-1]; the lumisphere at opt->probe. */
+int vr_probe_coeffs(vr_tree_t tree, const VrRenderOptions* opt, float* out_dev, void* stream);
+/* Async D2H of a pitched RGBA8 frame into tightly packed host memory. */
+int vr_read_back(void* host_rgba, const void* dev_rgba, int64_t pitch, int width, int height,
+                 void* stream);
+int vr_stream_sync(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOLREND_HIP_H_ */

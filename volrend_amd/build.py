@@ -1,0 +1,51 @@
+"""Builds libvolrend_hip.so (gfx950) in-tree with hipcc.
+
+    python -m volrend_amd.build [--force]
+
+-ffp-contract=off is part of the numerical contract (see csrc/vr_device_math.h).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libvolrend_hip.so")
+SOURCES = ["vr_kernels.hip", "vr_api.cpp"]
+HEADERS = ["vr_internal.h", "vr_device_math.h", os.path.join(ROOT, "include", "volrend_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off",                                # explicit fmaf only
+    "-fhip-fp32-correctly-rounded-divide-sqrt",         # IEEE / and sqrt, as nvcc's default
+    "-fno-gpu-flush-denormals-to-zero",
+    "-fno-fast-math",
+    "-x", "hip",
+]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [
+        h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    if not force and not needs_build():
+        return LIB
+    cmd = [HIPCC, *FLAGS, *extra_flags, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

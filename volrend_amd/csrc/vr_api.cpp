@@ -1,0 +1,425 @@
+// vr_api.cpp -- the C ABI of libvolrend_hip.so (include/volrend_hip.h).
+// Host side only: argument validation, device memory, launch set-up.
+// Built with hipcc for gfx950, -ffp-contract=off (the host-side Rodrigues
+// pre-computation below must round like the oracle).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "vr_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP,      \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,    \
+                        __LINE__);                                                          \
+    } while (0)
+
+}  // namespace
+
+struct VrTreeOpaque {
+    int device = 0;
+    int32_t* child = nullptr;
+    uint16_t* data = nullptr;
+    float* extra = nullptr;
+    uint32_t* status = nullptr;
+    float* probe_buf = nullptr;  // data_dim floats: the lumisphere at opt.probe
+    VrTreeDesc desc{};  // pointers cleared; scalars kept
+    int32_t max_depth = 0;
+    uint64_t device_bytes = 0;
+};
+
+namespace {
+
+// Walks the child links from the root: every link must land on a node that has
+// not been reached before (a tree, not a DAG / cycle), inside [1, capacity).
+// Returns the deepest leaf level or -1.  A malformed file would otherwise make
+// the device descent loop forever.
+int validate_topology(const int32_t* child, int64_t cap, int N3, char* why, size_t why_len) {
+    if (cap <= 0) {
+        snprintf(why, why_len, "capacity must be positive");
+        return -1;
+    }
+    std::vector<uint8_t> seen((size_t)cap, 0);
+    std::vector<int64_t> cur{0}, next;
+    seen[0] = 1;
+    int depth = 0;
+    for (;;) {
+        next.clear();
+        for (int64_t n : cur) {
+            const int32_t* c = child + n * N3;
+            for (int s = 0; s < N3; ++s) {
+                const int64_t skip = c[s];
+                if (skip == 0) continue;
+                const int64_t m = n + skip;
+                if (m <= 0 || m >= cap) {
+                    snprintf(why, why_len, "node %lld slot %d links outside the tree (%lld)",
+                             (long long)n, s, (long long)m);
+                    return -1;
+                }
+                if (seen[(size_t)m]) {
+                    snprintf(why, why_len, "node %lld is linked twice (cycle or DAG)", (long long)m);
+                    return -1;
+                }
+                seen[(size_t)m] = 1;
+                next.push_back(m);
+            }
+        }
+        if (next.empty()) break;
+        if (++depth > 60) {
+            snprintf(why, why_len, "tree deeper than 60 levels");
+            return -1;
+        }
+        cur.swap(next);
+    }
+    return depth;
+}
+
+// same rounding sequence as the oracle's norm3 (strict / fma)
+float host_norm3(const float* d, int fma) {
+    float s;
+    if (fma) {
+        s = std::fmaf(d[0], d[0], d[1] * d[1]);
+        s = std::fmaf(d[2], d[2], s);
+    } else {
+        s = d[0] * d[0] + d[1] * d[1];
+        s = d[2] * d[2] + s;
+    }
+    return std::sqrt(s);
+}
+
+void fill_tree_params(vr::KParams& k, const VrTreeOpaque* t) {
+    k.child = t->child;
+    k.data = t->data;
+    k.nodes = nullptr;
+    k.leaves = nullptr;
+    k.extra = t->extra;
+    for (int i = 0; i < 3; ++i) {
+        k.offset[i] = t->desc.offset[i];
+        k.scale[i] = t->desc.scale[i];
+    }
+    k.N = t->desc.N;
+    k.N3 = t->desc.N * t->desc.N * t->desc.N;
+    k.data_dim = t->desc.data_dim;
+    k.format = t->desc.format;
+    k.basis_dim = t->desc.basis_dim;
+    k.leaf_stride_h = t->desc.data_dim;
+    k.max_depth = t->max_depth;
+    k.ndc_width = t->desc.ndc_width;
+    k.ndc_height = t->desc.ndc_height;
+    k.ndc_focal = t->desc.ndc_focal;
+    k.status = t->status;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vr_abi_version(void) { return VR_ABI_VERSION; }
+
+const char* vr_last_error(void) { return g_err; }
+
+int vr_device_count(int* count) {
+    if (!count) return fail(VR_ERR_INVALID_ARGUMENT, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(VR_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return VR_OK;
+}
+
+int vr_set_device(int device) {
+    if (device < 0) return VR_OK;
+    HIP_TRY(hipSetDevice(device));
+    return VR_OK;
+}
+
+int vr_device_name(int device, char* name, size_t name_len) {
+    if (!name || name_len == 0) return fail(VR_ERR_INVALID_ARGUMENT, "name buffer is NULL");
+    hipDeviceProp_t prop;
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(name, name_len, "%s", prop.gcnArchName);
+    return VR_OK;
+}
+
+void vr_default_tree_desc(VrTreeDesc* d) {
+    if (!d) return;
+    memset(d, 0, sizeof(*d));
+    d->N = 2;
+    d->format = VR_FORMAT_RGBA;
+    d->basis_dim = -1;
+    d->ndc_width = -1.f;
+}
+
+int vr_tree_upload(const VrTreeDesc* d, vr_tree_t* out) {
+    if (!d || !out) return fail(VR_ERR_INVALID_ARGUMENT, "desc/out is NULL");
+    *out = nullptr;
+    if (!d->child || !d->data) return fail(VR_ERR_INVALID_ARGUMENT, "child/data is NULL");
+    if (d->N < 2 || d->N > 16) return fail(VR_ERR_INVALID_ARGUMENT, "N=%d out of range", d->N);
+    if (d->capacity <= 0) return fail(VR_ERR_INVALID_ARGUMENT, "capacity must be positive");
+    if (d->format < VR_FORMAT_RGBA || d->format > VR_FORMAT_ASG)
+        return fail(VR_ERR_INVALID_ARGUMENT, "unknown data format %d", d->format);
+    const int min_dim = d->format == VR_FORMAT_RGBA ? 4 : 3 * d->basis_dim + 1;
+    if (d->format != VR_FORMAT_RGBA && (d->basis_dim < 1 || d->basis_dim > VR_MAX_BASIS))
+        return fail(VR_ERR_INVALID_ARGUMENT, "basis_dim=%d out of range [1,%d]", d->basis_dim,
+                    VR_MAX_BASIS);
+    if (d->data_dim < min_dim)
+        return fail(VR_ERR_INVALID_ARGUMENT, "data_dim=%d too small for the format (need %d)",
+                    d->data_dim, min_dim);
+    if (d->format == VR_FORMAT_SG && (!d->extra || d->extra_count < (uint64_t)d->basis_dim * 4))
+        return fail(VR_ERR_INVALID_ARGUMENT, "SG needs basis_dim*4 extra floats");
+    if (d->format == VR_FORMAT_ASG && (!d->extra || d->extra_count < (uint64_t)d->basis_dim * 11))
+        return fail(VR_ERR_INVALID_ARGUMENT, "ASG needs basis_dim*11 extra floats");
+
+    const int N3 = d->N * d->N * d->N;
+    const size_t n_slots = (size_t)d->capacity * N3;
+    const size_t child_sz = n_slots * sizeof(int32_t);
+    const size_t data_sz = n_slots * (size_t)d->data_dim * sizeof(uint16_t);
+
+    // topology check needs the child words on the host
+    std::vector<int32_t> staged;
+    const int32_t* host_child = d->child;
+    if (d->memory == 1) {
+        staged.resize(n_slots);
+        HIP_TRY(hipMemcpy(staged.data(), d->child, child_sz, hipMemcpyDeviceToHost));
+        host_child = staged.data();
+    }
+    char why[256];
+    const int max_depth = validate_topology(host_child, d->capacity, N3, why, sizeof(why));
+    if (max_depth < 0) return fail(VR_ERR_BAD_TREE, "bad tree: %s", why);
+
+    VrTreeOpaque* t = new (std::nothrow) VrTreeOpaque();
+    if (!t) return fail(VR_ERR_OUT_OF_MEMORY, "host allocation failed");
+    t->desc = *d;
+    t->desc.child = nullptr;
+    t->desc.data = nullptr;
+    t->desc.extra = nullptr;
+    t->max_depth = max_depth;
+    hipError_t e = hipGetDevice(&t->device);
+    const hipMemcpyKind kind = d->memory == 1 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (e == hipSuccess) e = hipMalloc((void**)&t->child, child_sz);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->data, data_sz);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->status, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(t->status, 0, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&t->probe_buf, sizeof(float) * (size_t)d->data_dim);
+    if (e == hipSuccess) e = hipMemcpy(t->child, d->child, child_sz, kind);
+    if (e == hipSuccess) e = hipMemcpy(t->data, d->data, data_sz, kind);
+    t->device_bytes = child_sz + data_sz + sizeof(uint32_t);
+    if (e == hipSuccess && d->extra && d->extra_count) {
+        const size_t esz = (size_t)d->extra_count * sizeof(float);
+        e = hipMalloc((void**)&t->extra, esz);
+        if (e == hipSuccess) e = hipMemcpy(t->extra, d->extra, esz, kind);
+        t->device_bytes += esz;
+    }
+    if (e != hipSuccess) {
+        vr_tree_free(t);
+        return fail(e == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP,
+                    "tree upload failed: %s", hipGetErrorString(e));
+    }
+    *out = t;
+    return VR_OK;
+}
+
+int vr_tree_free(vr_tree_t t) {
+    if (!t) return VR_OK;
+    if (t->child) (void)hipFree(t->child);
+    if (t->data) (void)hipFree(t->data);
+    if (t->extra) (void)hipFree(t->extra);
+    if (t->status) (void)hipFree(t->status);
+    if (t->probe_buf) (void)hipFree(t->probe_buf);
+    delete t;
+    return VR_OK;
+}
+
+int vr_tree_info(vr_tree_t t, VrTreeInfo* info) {
+    if (!t || !info) return fail(VR_ERR_INVALID_ARGUMENT, "tree/info is NULL");
+    info->capacity = t->desc.capacity;
+    info->N = t->desc.N;
+    info->data_dim = t->desc.data_dim;
+    info->format = t->desc.format;
+    info->basis_dim = t->desc.basis_dim;
+    info->max_depth = t->max_depth;
+    info->device = t->device;
+    info->device_bytes = t->device_bytes;
+    info->leaf_stride = (uint64_t)t->desc.data_dim * 2u;
+    return VR_OK;
+}
+
+void vr_default_options(VrRenderOptions* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->step_size = 1e-4f;
+    o->sigma_thresh = 1e-2f;
+    o->stop_thresh = 1e-2f;
+    o->background_brightness = 1.f;
+    o->render_bbox[3] = o->render_bbox[4] = o->render_bbox[5] = 1.f;
+    o->basis_minmax[0] = 0;
+    o->basis_minmax[1] = VR_MAX_BASIS - 1;
+    o->grid_max_depth = 4;
+    o->probe[2] = 1.f;
+    o->probe_disp_size = 100;
+}
+
+void vr_default_frame(VrFrame* f) {
+    if (!f) return;
+    memset(f, 0, sizeof(*f));
+    f->offscreen = 1;
+    f->layout = VR_LAYOUT_FRAME;
+    f->world = 1;
+    f->fp_mode = VR_FP_STRICT;
+}
+
+static int tile_geometry(int width, int height, int tile_w, int tile_h, int* tw, int* th,
+                         int* tiles_x, int* tiles_y) {
+    if (width <= 0 || height <= 0) return fail(VR_ERR_INVALID_ARGUMENT, "empty image");
+    if (tile_w == 0 && tile_h == 0) {
+        tile_w = (width + 7) & ~7;
+        tile_h = (height + 7) & ~7;
+    }
+    if (tile_w <= 0 || tile_h <= 0 || (tile_w & 7) || (tile_h & 7))
+        return fail(VR_ERR_INVALID_ARGUMENT, "tile size %dx%d must be positive multiples of 8",
+                    tile_w, tile_h);
+    *tw = tile_w;
+    *th = tile_h;
+    *tiles_x = (width + tile_w - 1) / tile_w;
+    *tiles_y = (height + tile_h - 1) / tile_h;
+    return VR_OK;
+}
+
+int64_t vr_compact_bytes(int width, int height, int tile_w, int tile_h, int world) {
+    int tw, th, tx, ty;
+    if (tile_geometry(width, height, tile_w, tile_h, &tw, &th, &tx, &ty) != VR_OK) return -1;
+    if (world < 1) world = 1;
+    const int64_t n_tiles = (int64_t)tx * ty;
+    const int64_t per_rank = (n_tiles + world - 1) / world;
+    return per_rank * tw * th * 4;
+}
+
+int vr_render(vr_tree_t t, const VrCamera* cam, const VrRenderOptions* opt, const VrFrame* f,
+              void* stream) {
+    if (!t || !cam || !opt || !f) return fail(VR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!f->rgba) return fail(VR_ERR_INVALID_ARGUMENT, "frame->rgba is NULL");
+    if (f->fp_mode != VR_FP_STRICT && f->fp_mode != VR_FP_FMA)
+        return fail(VR_ERR_INVALID_ARGUMENT, "unknown fp_mode %d", f->fp_mode);
+    if (f->layout != VR_LAYOUT_FRAME && f->layout != VR_LAYOUT_COMPACT)
+        return fail(VR_ERR_INVALID_ARGUMENT, "unknown layout %d", f->layout);
+    const int world = f->world < 1 ? 1 : f->world;
+    if (f->rank < 0 || f->rank >= world)
+        return fail(VR_ERR_INVALID_ARGUMENT, "rank %d outside world %d", f->rank, world);
+
+    vr::KParams k;
+    memset(&k, 0, sizeof(k));
+    fill_tree_params(k, t);
+    memcpy(k.xf, cam->transform, sizeof(k.xf));
+    k.width = cam->width;
+    k.height = cam->height;
+    k.fx = cam->fx;
+    k.fy = cam->fy;
+    k.step_size = opt->step_size;
+    k.sigma_thresh = opt->sigma_thresh;
+    k.stop_thresh = opt->stop_thresh;
+    k.background_brightness = opt->background_brightness;
+    memcpy(k.bbox, opt->render_bbox, sizeof(k.bbox));
+    k.basis_min = opt->basis_minmax[0];
+    k.basis_max = opt->basis_minmax[1];
+    k.render_depth = opt->render_depth != 0;
+    k.enable_probe = opt->enable_probe != 0;
+    k.probe_disp_size = opt->probe_disp_size;
+    k.probe_coeffs = t->probe_buf;
+    if (k.enable_probe)  // launch_renderer's pre-kernel, volrend.cu:202-209
+        HIP_TRY(vr::launch_probe(k, opt->probe, t->probe_buf, static_cast<hipStream_t>(stream)));
+
+    // rodrigues (reference src/cuda/volrend.cu:57-71): angle/axis/cos/sin are
+    // uniform over the frame -> once here, with the oracle's rounding sequence
+    const float angle = host_norm3(opt->rot_dirs, f->fp_mode == VR_FP_FMA);
+    if ((double)angle < 1e-6) {
+        k.rot_enabled = 0;
+    } else {
+        k.rot_enabled = 1;
+        for (int i = 0; i < 3; ++i) k.rot_k[i] = opt->rot_dirs[i] / angle;
+        k.rot_cos = cosf(angle);
+        k.rot_sin = sinf(angle);
+    }
+
+    int rc = tile_geometry(cam->width, cam->height, f->tile_w, f->tile_h, &k.tile_w, &k.tile_h,
+                           &k.tiles_x, &k.tiles_y);
+    if (rc != VR_OK) return rc;
+    const int64_t n_tiles = (int64_t)k.tiles_x * k.tiles_y;
+    k.rank = f->rank;
+    k.world = world;
+    k.n_local_tiles = (int32_t)((n_tiles - f->rank + world - 1) / world);
+    k.wblocks_per_tile_x = k.tile_w / 8;
+    k.wblocks_per_tile = (k.tile_w / 8) * (k.tile_h / 8);
+    k.n_wave_blocks = (int64_t)k.n_local_tiles * k.wblocks_per_tile;
+    k.rgba = static_cast<uint8_t*>(f->rgba);
+    k.pitch = f->pitch ? f->pitch : (int64_t)cam->width * 4;
+    k.depth = f->depth;
+    k.accum = f->accum;
+    k.offscreen = f->offscreen != 0;
+    k.layout = f->layout;
+
+    HIP_TRY(vr::launch_render(k, f->fp_mode, static_cast<hipStream_t>(stream)));
+    return VR_OK;
+}
+
+int vr_assemble_tiles(void* frame_rgba, int64_t pitch, const void* gathered, int width, int height,
+                      int tile_w, int tile_h, int world, void* stream) {
+    if (!frame_rgba || !gathered) return fail(VR_ERR_INVALID_ARGUMENT, "NULL buffer");
+    int tw, th, tx, ty;
+    int rc = tile_geometry(width, height, tile_w, tile_h, &tw, &th, &tx, &ty);
+    if (rc != VR_OK) return rc;
+    if (world < 1) world = 1;
+    HIP_TRY(vr::launch_assemble(static_cast<uint8_t*>(frame_rgba), pitch ? pitch : (int64_t)width * 4,
+                                static_cast<const uint8_t*>(gathered), width, height, tw, th,
+                                world, static_cast<hipStream_t>(stream)));
+    return VR_OK;
+}
+
+int vr_probe_coeffs(vr_tree_t t, const VrRenderOptions* opt, float* out_dev, void* stream) {
+    if (!t || !opt || !out_dev) return fail(VR_ERR_INVALID_ARGUMENT, "NULL argument");
+    vr::KParams k;
+    memset(&k, 0, sizeof(k));
+    fill_tree_params(k, t);
+    HIP_TRY(vr::launch_probe(k, opt->probe, out_dev, static_cast<hipStream_t>(stream)));
+    return VR_OK;
+}
+
+int vr_read_back(void* host_rgba, const void* dev_rgba, int64_t pitch, int width, int height,
+                 void* stream) {
+    if (!host_rgba || !dev_rgba) return fail(VR_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (pitch == 0) pitch = (int64_t)width * 4;
+    HIP_TRY(hipMemcpy2DAsync(host_rgba, (size_t)width * 4, dev_rgba, (size_t)pitch,
+                             (size_t)width * 4, (size_t)height, hipMemcpyDeviceToHost,
+                             static_cast<hipStream_t>(stream)));
+    return VR_OK;
+}
+
+int vr_stream_sync(void* stream) {
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return VR_OK;
+}
+
+}  // extern "C"

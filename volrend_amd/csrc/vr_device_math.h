@@ -1,0 +1,126 @@
+// vr_device_math.h -- gfx950 device math for the ray-march kernel.
+//
+// The kernel is compiled with -ffp-contract=off: every fused multiply-add in
+// here is spelled __builtin_fmaf explicitly, so the rounding of each operation
+// is a property of this source and not of the optimiser.  Policy<0> ("strict")
+// rounds after every operator exactly as the reference source reads
+// (include/volrend/cuda/rt_core.cuh, internal/lumisphere.hpp, cuda/common.cuh);
+// Policy<1> fuses a*b+c where an nvcc -fmad=true build plausibly does
+// (DESIGN.md "FP contract" lists the rules and every site).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vr {
+
+template <int FMA>
+struct Policy;
+
+template <>
+struct Policy<0> {
+    static __device__ __forceinline__ float madd(float a, float b, float c) { return a * b + c; }
+    static __device__ __forceinline__ float msub(float a, float b, float c) { return a * b - c; }
+    static __device__ __forceinline__ float nmadd(float a, float b, float c) { return c - a * b; }
+    static __device__ __forceinline__ double dmadd(double a, double b, double c) { return a * b + c; }
+    static __device__ __forceinline__ double dmsub(double a, double b, double c) { return a * b - c; }
+};
+template <>
+struct Policy<1> {
+    static __device__ __forceinline__ float madd(float a, float b, float c) {
+        return __builtin_fmaf(a, b, c);
+    }
+    static __device__ __forceinline__ float msub(float a, float b, float c) {
+        return __builtin_fmaf(a, b, -c);
+    }
+    static __device__ __forceinline__ float nmadd(float a, float b, float c) {
+        return __builtin_fmaf(-a, b, c);
+    }
+    static __device__ __forceinline__ double dmadd(double a, double b, double c) {
+        return __builtin_fma(a, b, c);
+    }
+    static __device__ __forceinline__ double dmsub(double a, double b, double c) {
+        return __builtin_fma(a, b, -c);
+    }
+};
+
+// PTX min.f32 / max.f32 semantics == v_min_f32 / v_max_f32: NaN loses, -0 < +0.
+static __device__ __forceinline__ float vmin(float a, float b) { return __builtin_fminf(a, b); }
+static __device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
+
+static __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+static __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+
+// binary16 bits -> binary32, exact (v_cvt_f32_f16)
+static __device__ __forceinline__ float h2f(uint16_t h) {
+    return (float)__builtin_bit_cast(_Float16, h);
+}
+
+// vr_expf: the deterministic expf of DESIGN.md.  The reference calls CUDA's
+// expf (rt_core.cuh:119,160), whose bits depend on NVIDIA's ex2.approx; this is
+// a pure IEEE-op algorithm so host oracle and device agree bit for bit:
+//   clamp to [-104, 89]; k = rint(x*log2e); r = x - k*ln2 (two-step Cody-Waite);
+//   degree-5 Horner (Cephes coefficients); result = (y*2^(k>>1)) * 2^(k-(k>>1)).
+static __device__ __forceinline__ float vr_expf(float x) {
+    if (x != x) return x;
+    x = x < -104.0f ? -104.0f : x;
+    x = x > 89.0f ? 89.0f : x;
+    const float kf = __builtin_rintf(x * 1.44269502162933349609375f);
+    float r = __builtin_fmaf(kf, -0.693145751953125f, x);
+    r = __builtin_fmaf(kf, -1.428606765330187045037746429443359375e-06f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    float y = __builtin_fmaf(p, r2, r);
+    y = y + 1.0f;
+    const int k = (int)kf;
+    const int k1 = k >> 1;
+    const int k2 = k - k1;
+    const float s1 = u2f((uint32_t)(k1 + 127) << 23);
+    const float s2 = u2f((uint32_t)(k2 + 127) << 23);
+    return (y * s1) * s2;
+}
+
+template <int FMA>
+static __device__ __forceinline__ float norm3(const float* d) {
+    using P = Policy<FMA>;
+    float s = P::madd(d[0], d[0], d[1] * d[1]);
+    s = P::madd(d[2], d[2], s);
+    return __builtin_sqrtf(s);
+}
+
+template <int FMA>
+static __device__ __forceinline__ void normalize3(float* d) {
+    const float inv = 1.f / norm3<FMA>(d);
+    d[0] *= inv;
+    d[1] *= inv;
+    d[2] *= inv;
+}
+
+// column-major 3x3 (first 9 floats of the 4x3 c2w) times vector
+template <int FMA>
+static __device__ __forceinline__ void mv3(const float* m, const float* v, float* out) {
+    using P = Policy<FMA>;
+    out[0] = P::madd(m[6], v[2], P::madd(m[0], v[0], m[3] * v[1]));
+    out[1] = P::madd(m[7], v[2], P::madd(m[1], v[0], m[4] * v[1]));
+    out[2] = P::madd(m[8], v[2], P::madd(m[2], v[0], m[5] * v[1]));
+}
+
+template <int FMA>
+static __device__ __forceinline__ float dot3(const float* u, const float* v) {
+    using P = Policy<FMA>;
+    return P::madd(u[2], v[2], P::madd(u[0], v[0], u[1] * v[1]));
+}
+
+template <int FMA>
+static __device__ __forceinline__ void cross3(const float* a, const float* b, float* out) {
+    using P = Policy<FMA>;
+    out[0] = P::msub(a[1], b[2], a[2] * b[1]);
+    out[1] = P::msub(a[2], b[0], a[0] * b[2]);
+    out[2] = P::msub(a[0], b[1], a[1] * b[0]);
+}
+
+}  // namespace vr

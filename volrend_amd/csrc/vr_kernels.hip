@@ -1,0 +1,586 @@
+// vr_kernels.hip -- gfx950 (CDNA4) PlenOctree ray-march kernels.
+//
+// Replaces the reference's device path: device::render_kernel
+// (src/cuda/volrend.cu:78-173) with trace_ray (include/volrend/cuda/rt_core.cuh:66-196),
+// query_single_from_root (include/volrend/internal/n3tree_query.hpp:13-48) and
+// maybe_precalc_basis (include/volrend/internal/lumisphere.hpp:9-87) -- written
+// from the algorithm, not from the CUDA text: wave64 8x8 pixel tiles, integer
+// digit descent for N=2 (bit-identical to the float descent, see query_n2),
+// deterministic expf, explicit FP contraction policy.
+//
+// Built with -ffp-contract=off; see vr_device_math.h.
+#include "vr_device_math.h"
+#include "vr_internal.h"
+
+namespace vr {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kMaxIter = 1 << 22;  // guard against step_size <= 0 (upstream would spin forever)
+
+enum { BASIS_RGBA = -1, BASIS_1 = 1, BASIS_4 = 4, BASIS_9 = 9, BASIS_16 = 16, BASIS_25 = 25 };
+
+// ---------------------------------------------------------------------------
+// view-dependent basis, lumisphere.hpp:9-87 (double literals => FP64 products)
+// ---------------------------------------------------------------------------
+// LOBES=false compiles the SH branch only (the hot configuration keeps zero
+// scratch); LOBES=true adds the SG / ASG lobes read from tree.extra.
+template <int FMA, bool LOBES>
+__device__ __forceinline__ void precalc_basis(const KParams& p, const float* dir, float* out) {
+    using P = Policy<FMA>;
+    const int basis_dim = p.basis_dim;
+    // NB: every index into out[] is a compile-time constant (loops fully
+    // unrolled, predicated on basis_dim) so the array stays in VGPRs.
+    if (LOBES && p.format == VR_FORMAT_ASG) {  // lumisphere.hpp:14-29
+#pragma unroll
+        for (int i = 0; i < VR_MAX_BASIS; ++i) {
+            if (i < basis_dim) {
+                const float* ptr = p.extra + i * 11;
+                const float S = dot3<FMA>(dir, ptr + 8);
+                const float dot_x = dot3<FMA>(dir, ptr + 2);
+                const float dot_y = dot3<FMA>(dir, ptr + 5);
+                const float arg = P::msub(-ptr[0] * dot_x, dot_x, ptr[1] * dot_y * dot_y);
+                out[i] = S * vr_expf(arg) / (float)basis_dim;
+            }
+        }
+    } else if (LOBES && p.format == VR_FORMAT_SG) {  // lumisphere.hpp:30-37
+#pragma unroll
+        for (int i = 0; i < VR_MAX_BASIS; ++i) {
+            if (i < basis_dim) {
+                const float* ptr = p.extra + i * 4;
+                out[i] = vr_expf(ptr[0] * (dot3<FMA>(dir, ptr + 1) - 1.f)) / (float)basis_dim;
+            }
+        }
+    } else if (p.format == VR_FORMAT_SH) {  // lumisphere.hpp:38-81
+        out[0] = (float)0.28209479177387814;
+        const float x = dir[0], y = dir[1], z = dir[2];
+        const float xx = x * x, yy = y * y, zz = z * z;
+        const float xy = x * y, yz = y * z, xz = x * z;
+        if (basis_dim == 25) {
+            out[16] = (float)(2.5033429417967046 * (double)xy * (double)(xx - yy));
+            out[17] = (float)(-1.7701307697799304 * (double)yz * (double)P::msub(3.f, xx, yy));
+            out[18] = (float)(0.9461746957575601 * (double)xy * (double)P::msub(7.f, zz, 1.f));
+            out[19] = (float)(-0.6690465435572892 * (double)yz * (double)P::msub(7.f, zz, 3.f));
+            out[20] = (float)(0.10578554691520431 *
+                              (double)P::madd(zz, P::msub(35.f, zz, 30.f), 3.f));
+            out[21] = (float)(-0.6690465435572892 * (double)xz * (double)P::msub(7.f, zz, 3.f));
+            out[22] =
+                (float)(0.47308734787878004 * (double)(xx - yy) * (double)P::msub(7.f, zz, 1.f));
+            out[23] = (float)(-1.7701307697799304 * (double)xz * (double)P::nmadd(3.f, yy, xx));
+            const float a = P::nmadd(3.f, yy, xx);
+            const float b = P::msub(3.f, xx, yy);
+            out[24] = (float)(0.6258357354491761 * (double)P::msub(xx, a, yy * b));
+        }
+        if (basis_dim == 25 || basis_dim == 16) {
+            out[9] = (float)(-0.5900435899266435 * (double)y * (double)P::msub(3.f, xx, yy));
+            out[10] = (float)(2.890611442640554 * (double)xy * (double)z);
+            out[11] = (float)(-0.4570457994644658 * (double)y * (double)(P::msub(4.f, zz, xx) - yy));
+            out[12] = (float)(0.3731763325901154 * (double)z *
+                              (double)P::nmadd(3.f, yy, P::msub(2.f, zz, 3.f * xx)));
+            out[13] = (float)(-0.4570457994644658 * (double)x * (double)(P::msub(4.f, zz, xx) - yy));
+            out[14] = (float)(1.445305721320277 * (double)z * (double)(xx - yy));
+            out[15] = (float)(-0.5900435899266435 * (double)x * (double)P::nmadd(3.f, yy, xx));
+        }
+        if (basis_dim == 25 || basis_dim == 16 || basis_dim == 9) {
+            out[4] = (float)(1.0925484305920792 * (double)xy);
+            out[5] = (float)(-1.0925484305920792 * (double)yz);
+            out[6] = (float)(0.31539156525252005 *
+                             (P::dmsub(2.0, (double)zz, (double)xx) - (double)yy));
+            out[7] = (float)(-1.0925484305920792 * (double)xz);
+            out[8] = (float)(0.5462742152960396 * (double)(xx - yy));
+        }
+        if (basis_dim == 25 || basis_dim == 16 || basis_dim == 9 || basis_dim == 4) {
+            out[1] = (float)(-0.4886025119029199 * (double)y);
+            out[2] = (float)(0.4886025119029199 * (double)z);
+            out[3] = (float)(-0.4886025119029199 * (double)x);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// octree point query, n3tree_query.hpp:13-48
+// ---------------------------------------------------------------------------
+// Literal float descent (any N).  pos is rewritten to leaf-local coordinates.
+template <int FMA>
+__device__ __forceinline__ int64_t query_generic(const KParams& p, float* xyz, float* cube_sz) {
+    using P = Policy<FMA>;
+    const float fN = (float)p.N;
+    const float hi = 1.f - 1e-6f;
+    for (int i = 0; i < 3; ++i) xyz[i] = vmax(vmin(xyz[i], hi), 0.f);
+    int64_t ptr = 0;
+    *cube_sz = fN;
+    for (int guard = 0; guard < 64; ++guard) {
+        float index = 0.f;
+        for (int i = 0; i < 3; ++i) {
+            xyz[i] *= fN;
+            const float k = __builtin_floorf(xyz[i]);
+            index = P::madd(index, fN, k);
+            xyz[i] -= k;
+        }
+        const int64_t sub_ptr = ptr + (int32_t)index;
+        const int64_t skip = p.child[sub_ptr];
+        if (skip == 0) return sub_ptr;
+        *cube_sz *= fN;
+        ptr += skip * p.N3;
+    }
+    return ptr;  // unreachable for a validated tree
+}
+
+// N == 2: the float recurrence {x*=2; k=floor(x); x-=k} is exact in binary32,
+// so the level-l digit is bit (23-l) of floor(x * 2^24) and the leaf-local
+// coordinate is fract(x * 2^(l+1)) -- same leaf, same bits, no float chain.
+// Valid while the deepest leaf has l <= 23 (checked at upload).
+__device__ __forceinline__ int64_t query_n2(const KParams& p, float* xyz, float* cube_sz) {
+    const float hi = 1.f - 1e-6f;
+    xyz[0] = vmax(vmin(xyz[0], hi), 0.f);
+    xyz[1] = vmax(vmin(xyz[1], hi), 0.f);
+    xyz[2] = vmax(vmin(xyz[2], hi), 0.f);
+    const uint32_t ux = (uint32_t)(xyz[0] * 16777216.f);
+    const uint32_t uy = (uint32_t)(xyz[1] * 16777216.f);
+    const uint32_t uz = (uint32_t)(xyz[2] * 16777216.f);
+    uint32_t node = 0;
+    int l = 0;
+    uint32_t slot;
+    for (;; ++l) {
+        const int sh = 23 - l;
+        slot = (((ux >> sh) & 1u) << 2) | (((uy >> sh) & 1u) << 1) | ((uz >> sh) & 1u);
+        const int32_t skip = p.child[(uint64_t)node * 8u + slot];
+        if (skip == 0 || l >= 23) break;
+        node += (uint32_t)skip;
+    }
+    const float cs = u2f((uint32_t)(127 + l + 1) << 23);  // 2^(l+1)
+    *cube_sz = cs;
+    xyz[0] = __builtin_amdgcn_fractf(xyz[0] * cs);
+    xyz[1] = __builtin_amdgcn_fractf(xyz[1] * cs);
+    xyz[2] = __builtin_amdgcn_fractf(xyz[2] * cs);
+    return (int64_t)node * 8 + slot;
+}
+
+// rt_core.cuh:37-49
+template <int FMA>
+__device__ __forceinline__ float dda_unit(const float* cen, const float* invdir) {
+    using P = Policy<FMA>;
+    float tmax = 1e4f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float t1 = -cen[i] * invdir[i];
+        const float t2 = FMA ? P::madd(-cen[i], invdir[i], invdir[i]) : (t1 + invdir[i]);
+        tmax = vmin(tmax, vmax(t1, t2));
+    }
+    return tmax;
+}
+
+// SH / SG colour of one channel: rt_core.cuh:125-165.  Group order 25 -> 16 -> 9
+// -> 4, each group summed left to right, then added to tmp.
+template <int FMA, int BASIS>
+__device__ __forceinline__ float channel_dot(const float* basis_fn, const uint16_t* v) {
+    using P = Policy<FMA>;
+    float tmp = basis_fn[0] * h2f(v[0]);
+    if (BASIS == 25) {
+        float g = P::madd(basis_fn[16], h2f(v[16]), basis_fn[17] * h2f(v[17]));
+#pragma unroll
+        for (int i = 18; i <= 24; ++i) g = P::madd(basis_fn[i], h2f(v[i]), g);
+        tmp += g;
+    }
+    if (BASIS >= 16) {
+        float g = P::madd(basis_fn[9], h2f(v[9]), basis_fn[10] * h2f(v[10]));
+#pragma unroll
+        for (int i = 11; i <= 15; ++i) g = P::madd(basis_fn[i], h2f(v[i]), g);
+        tmp += g;
+    }
+    if (BASIS >= 9) {
+        float g = P::madd(basis_fn[4], h2f(v[4]), basis_fn[5] * h2f(v[5]));
+#pragma unroll
+        for (int i = 6; i <= 8; ++i) g = P::madd(basis_fn[i], h2f(v[i]), g);
+        tmp += g;
+    }
+    if (BASIS >= 4) {
+        float g = P::madd(basis_fn[1], h2f(v[1]), basis_fn[2] * h2f(v[2]));
+        g = P::madd(basis_fn[3], h2f(v[3]), g);
+        tmp += g;
+    }
+    return tmp;
+}
+
+// ---------------------------------------------------------------------------
+// trace_ray, rt_core.cuh:66-196
+// ---------------------------------------------------------------------------
+template <int FMA, int BASIS, bool N2, bool LOBES>
+__device__ __forceinline__ void trace_ray(const KParams& p, float* dir, const float* vdir, const float* cen,
+                          float tmax_bg, float* out) {
+    using P = Policy<FMA>;
+    // _get_delta_scale, rt_core.cuh:52-63
+    dir[0] *= p.scale[0];
+    dir[1] *= p.scale[1];
+    dir[2] *= p.scale[2];
+    const float delta_scale = 1.f / norm3<FMA>(dir);
+    dir[0] *= delta_scale;
+    dir[1] *= delta_scale;
+    dir[2] *= delta_scale;
+    tmax_bg /= delta_scale;
+
+    float invdir[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) invdir[i] = (float)(1.0 / ((double)dir[i] + 1e-9));
+
+    // _dda_world, rt_core.cuh:18-34: the 1e-6 literals make this FP64
+    float tmin = 0.0f, tmax = 1e4f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float t1 =
+            (float)((((double)p.bbox[i] + 1e-6) - (double)cen[i]) * (double)invdir[i]);
+        const float t2 =
+            (float)((((double)p.bbox[i + 3] - 1e-6) - (double)cen[i]) * (double)invdir[i]);
+        tmin = vmax(tmin, vmin(t1, t2));
+        tmax = vmin(tmax, vmax(t1, t2));
+    }
+    tmax = vmin(tmax, tmax_bg);
+
+    if (tmax < 0 || tmin > tmax) {
+        if (p.render_depth) out[3] = 1.f;
+        return;
+    }
+
+    float basis_fn[VR_MAX_BASIS];
+#pragma unroll
+    for (int i = 0; i < VR_MAX_BASIS; ++i) basis_fn[i] = 0.f;
+    if (BASIS != BASIS_RGBA) {
+        precalc_basis<FMA, LOBES>(p, vdir, basis_fn);
+#pragma unroll
+        for (int i = 0; i < VR_MAX_BASIS; ++i)
+            if (i < p.basis_min || i > p.basis_max) basis_fn[i] = 0.f;
+    }
+
+    const int data_dim = p.data_dim;
+    const int bstride = p.basis_dim;
+    float light = 1.f;
+    float t = tmin;
+    int iter = 0;
+    while (t < tmax) {
+        float pos[3];
+        pos[0] = P::madd(t, dir[0], cen[0]);
+        pos[1] = P::madd(t, dir[1], cen[1]);
+        pos[2] = P::madd(t, dir[2], cen[2]);
+
+        float cube_sz;
+        const int64_t leaf = N2 ? query_n2(p, pos, &cube_sz) : query_generic<FMA>(p, pos, &cube_sz);
+        const uint16_t* v = p.data + leaf * data_dim;
+
+        const float t_subcube = dda_unit<FMA>(pos, invdir) / cube_sz;
+        const float delta_t = t_subcube + p.step_size;
+        const float sigma = h2f(v[data_dim - 1]);
+        if (sigma > p.sigma_thresh) {
+            const float att = vr_expf(-delta_t * delta_scale * sigma);
+            const float weight = light * (1.f - att);
+            if (p.render_depth) {
+                out[0] = P::madd(weight, t, out[0]);
+            } else if (BASIS != BASIS_RGBA) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float tmp = channel_dot<FMA, BASIS>(basis_fn, v + c * bstride);
+                    out[c] += weight / (1.f + vr_expf(-tmp));
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) out[c] = P::madd(h2f(v[c]), weight, out[c]);
+            }
+            light *= att;
+            if (light < p.stop_thresh) {
+                if (p.render_depth) out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
+                const float scale = 1.f / (1.f - light);
+                out[0] *= scale;
+                out[1] *= scale;
+                out[2] *= scale;
+                out[3] = 1.f;
+                return;
+            }
+        }
+        t += delta_t;
+        if (++iter >= kMaxIter) {
+            if (p.status) atomicOr(p.status, 1u);
+            break;
+        }
+    }
+    if (p.render_depth) {
+        out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
+        out[3] = 1.f;
+    } else {
+        out[3] = 1.f - light;
+    }
+}
+
+__device__ __forceinline__ uint32_t quant8(float v) {
+    // float -> uint8 the way a host build of the reference converts
+    // (truncate to int32, keep the low byte); volrend.cu:166
+    const float s = v * 255.f;
+    if (s != s) return 0u;
+    if (s >= 2147483648.f || s < -2147483648.f) return 0u;
+    return (uint32_t)(int32_t)s & 0xFFu;
+}
+
+// ---------------------------------------------------------------------------
+// render_kernel, volrend.cu:78-173.  One wave = one 8x8 pixel block.
+// ---------------------------------------------------------------------------
+template <int FMA, int BASIS, bool N2, bool LOBES>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void render_kernel(const KParams p) {
+    using P = Policy<FMA>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wb = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (wb >= p.n_wave_blocks) return;
+    // wave block -> local tile -> frame tile -> pixel
+    const int32_t k = (int32_t)(wb / p.wblocks_per_tile);
+    const int32_t sub = (int32_t)(wb - (int64_t)k * p.wblocks_per_tile);
+    const int32_t tile = k * p.world + p.rank;
+    const int32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    const int32_t sy = sub / p.wblocks_per_tile_x, sx = sub - sy * p.wblocks_per_tile_x;
+    const int32_t lx = sx * 8 + (lane & 7), ly = sy * 8 + (lane >> 3);  // within tile
+    const int32_t x = tx * p.tile_w + lx, y = ty * p.tile_h + ly;
+    if (x >= p.width || y >= p.height) return;
+
+    uint8_t* px;
+    if (p.layout == VR_LAYOUT_COMPACT)
+        px = p.rgba + ((int64_t)k * p.tile_w * p.tile_h + (int64_t)ly * p.tile_w + lx) * 4;
+    else
+        px = p.rgba + (int64_t)y * p.pitch + (int64_t)x * 4;
+    const int64_t pix = (int64_t)y * p.width + x;
+
+    uint32_t init = 0;
+    if (!p.offscreen) init = *reinterpret_cast<const uint32_t*>(px);
+
+    float dir[3], cen[3], out[4] = {0.f, 0.f, 0.f, 0.f};
+    // The probe circle (volrend.cu:100-134) is drawn by probe_overlay_kernel after this
+    // kernel: circle pixels end with out[3]=1, i.e. they do not depend on anything here.
+    const bool enable_draw = p.N > 0;
+    if (enable_draw) {
+        // screen2worlddir, volrend.cu:22-32 (no +0.5 pixel centre offset)
+        float xyz[3];
+        xyz[0] = P::nmadd(0.5f, (float)p.width, (float)x) / p.fx;
+        xyz[1] = -(P::nmadd(0.5f, (float)p.height, (float)y)) / p.fy;
+        xyz[2] = -1.0f;
+        mv3<FMA>(p.xf, xyz, dir);
+        normalize3<FMA>(dir);
+        cen[0] = p.xf[9];
+        cen[1] = p.xf[10];
+        cen[2] = p.xf[11];
+        float vdir[3] = {dir[0], dir[1], dir[2]};
+
+        if (p.ndc_width > 0) {  // maybe_world2ndc, volrend.cu:34-54
+            const float t = -(1.f + cen[2]) / dir[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) cen[i] = P::madd(t, dir[i], cen[i]);
+            dir[0] = -((2.f * p.ndc_focal) / p.ndc_width) * (dir[0] / dir[2] - cen[0] / cen[2]);
+            dir[1] = -((2.f * p.ndc_focal) / p.ndc_height) * (dir[1] / dir[2] - cen[1] / cen[2]);
+            dir[2] = -2.f / cen[2];
+            cen[0] = -((2.f * p.ndc_focal) / p.ndc_width) * (cen[0] / cen[2]);
+            cen[1] = -((2.f * p.ndc_focal) / p.ndc_height) * (cen[1] / cen[2]);
+            cen[2] = 1.f + 2.f / cen[2];
+            normalize3<FMA>(dir);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cen[i] = P::madd(p.scale[i], cen[i], p.offset[i]);
+
+        float t_max = 1e9f;
+        if (!p.offscreen && p.depth) t_max = p.depth[pix];
+
+        if (p.rot_enabled) {  // rodrigues, volrend.cu:57-71 (uniform part done on host)
+            float cr[3];
+            cross3<FMA>(p.rot_k, vdir, cr);
+            const float dot = dot3<FMA>(p.rot_k, vdir);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float a = P::madd(vdir[i], p.rot_cos, cr[i] * p.rot_sin);
+                const double kd = (double)(p.rot_k[i] * dot);
+                const double om = 1.0 - (double)p.rot_cos;
+                vdir[i] = (float)P::dmadd(kd, om, (double)a);
+            }
+        }
+        trace_ray<FMA, BASIS, N2, LOBES>(p, dir, vdir, cen, t_max, out);
+    }
+    if (p.accum) {
+        float4 a = make_float4(out[0], out[1], out[2], out[3]);
+        reinterpret_cast<float4*>(p.accum)[pix] = a;
+    }
+    // composite, volrend.cu:152-172
+    const float nalpha = 1.f - out[3];
+    if (p.offscreen) {
+        out[0] = P::madd(p.background_brightness, nalpha, out[0]);
+        out[1] = P::madd(p.background_brightness, nalpha, out[1]);
+        out[2] = P::madd(p.background_brightness, nalpha, out[2]);
+    } else {
+        out[0] = P::madd((float)(init & 0xFFu) / 255.f, nalpha, out[0]);
+        out[1] = P::madd((float)((init >> 8) & 0xFFu) / 255.f, nalpha, out[1]);
+        out[2] = P::madd((float)((init >> 16) & 0xFFu) / 255.f, nalpha, out[2]);
+    }
+    const uint32_t rgba =
+        quant8(out[0]) | (quant8(out[1]) << 8) | (quant8(out[2]) << 16) | 0xFF000000u;
+    *reinterpret_cast<uint32_t*>(px) = rgba;
+}
+
+// Probe circle overlay, volrend.cu:100-134.  Pixels inside the circle skip the
+// ray march (enable_draw=false) and end with alpha 1, so they are independent of
+// the main kernel's result and simply overwrite it.  One thread per pixel of the
+// (probe_disp_size+5)^2 corner square.
+template <int FMA>
+__global__ void probe_overlay_kernel(const KParams p) {
+    using P = Policy<FMA>;
+    const int side = p.probe_disp_size + 5;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= side * side) return;
+    const int y = idx / side;
+    const int x = p.width - side + (idx - y * side);
+    if (x < 0 || x >= p.width || y >= p.height) return;
+    // which tile / rank owns this pixel
+    const int tx = x / p.tile_w, ty = y / p.tile_h;
+    const int tile = ty * p.tiles_x + tx;
+    if (tile % p.world != p.rank) return;
+    float cen[3], dir[3], out[4] = {0.f, 0.f, 0.f, 0.f};
+    const int xx = x - (p.width - p.probe_disp_size) + 5;
+    const int yy = y - 5;
+    cen[0] = -((float)xx / (0.5f * (float)p.probe_disp_size) - 1.f);
+    cen[1] = ((float)yy / (0.5f * (float)p.probe_disp_size) - 1.f);
+    const float c = P::madd(cen[0], cen[0], cen[1] * cen[1]);
+    if (!(c <= 1.f)) return;
+    if (p.basis_dim >= 0) {
+        float basis_fn[VR_MAX_BASIS];
+#pragma unroll
+        for (int i = 0; i < VR_MAX_BASIS; ++i) basis_fn[i] = 0.f;
+        cen[2] = -__builtin_sqrtf(1 - c);
+        mv3<FMA>(p.xf, cen, dir);
+        precalc_basis<FMA, true>(p, dir, basis_fn);
+        // upstream indexes past basis_dim with the default basis_minmax {0,24} (UB);
+        // like the oracle, clamp to the coefficients that exist
+        int hi = p.basis_max;
+        if (hi > p.basis_dim - 1) hi = p.basis_dim - 1;
+        const int lo = p.basis_min < 0 ? 0 : p.basis_min;
+        for (int tt = 0; tt < 3; ++tt) {
+            const int off = tt * p.basis_dim;
+            float tmp = 0.f;
+            for (int i = lo; i <= hi; ++i) tmp = P::madd(basis_fn[i], p.probe_coeffs[off + i], tmp);
+            out[tt] = 1.f / (1.f + vr_expf(-tmp));
+        }
+    } else {
+        for (int i = 0; i < 3; ++i) out[i] = p.probe_coeffs[i];
+    }
+    out[3] = 1.f;
+    const int64_t pix = (int64_t)y * p.width + x;
+    if (p.accum) reinterpret_cast<float4*>(p.accum)[pix] = make_float4(out[0], out[1], out[2], out[3]);
+    // nalpha = 1 - out[3] = 0: the composite adds (+0 * anything) and leaves out[] as is
+    uint8_t* px;
+    if (p.layout == VR_LAYOUT_COMPACT) {
+        const int k = tile / p.world;
+        const int lx = x - tx * p.tile_w, ly = y - ty * p.tile_h;
+        px = p.rgba + ((int64_t)k * p.tile_w * p.tile_h + (int64_t)ly * p.tile_w + lx) * 4;
+    } else {
+        px = p.rgba + (int64_t)y * p.pitch + (int64_t)x * 4;
+    }
+    *reinterpret_cast<uint32_t*>(px) =
+        quant8(out[0]) | (quant8(out[1]) << 8) | (quant8(out[2]) << 16) | 0xFF000000u;
+}
+
+// retrieve_cursor_lumisphere_kernel, volrend.cu:175-191
+__global__ void probe_kernel(const KParams p, float probe0, float probe1, float probe2,
+                             float* out) {
+    float cen[3] = {p.offset[0] + p.scale[0] * probe0, p.offset[1] + p.scale[1] * probe1,
+                    p.offset[2] + p.scale[2] * probe2};
+    float cube_sz;
+    const int64_t leaf = query_generic<0>(p, cen, &cube_sz);
+    const uint16_t* v = p.data + leaf * p.data_dim;
+    for (int i = threadIdx.x; i < p.data_dim - 1; i += blockDim.x) out[i] = h2f(v[i]);
+}
+
+// De-interleave `world` gathered COMPACT buffers into the frame.
+__global__ void assemble_kernel(uint8_t* frame, int64_t pitch, const uint8_t* gathered, int width,
+                                int height, int tile_w, int tile_h, int tiles_x, int world,
+                                int64_t tiles_per_rank) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= width || y >= height) return;
+    const int tx = x / tile_w, ty = y / tile_h;
+    const int tile = ty * tiles_x + tx;
+    const int rank = tile % world;
+    const int64_t k = tile / world;
+    const int lx = x - tx * tile_w, ly = y - ty * tile_h;
+    const int64_t src = ((rank * tiles_per_rank + k) * tile_w * tile_h + (int64_t)ly * tile_w + lx);
+    *reinterpret_cast<uint32_t*>(frame + (int64_t)y * pitch + (int64_t)x * 4) =
+        reinterpret_cast<const uint32_t*>(gathered)[src];
+}
+
+template <int FMA, bool N2, bool LOBES>
+hipError_t launch_basis(const KParams& p, dim3 grid, dim3 block, hipStream_t s) {
+    int b;
+    if (p.basis_dim < 0 || p.format == VR_FORMAT_RGBA) {
+        b = BASIS_RGBA;
+    } else {
+        switch (p.basis_dim) {  // the reference's switch only knows 25/16/9/4 (rt_core.cuh:132-160)
+            case 25: b = BASIS_25; break;
+            case 16: b = BASIS_16; break;
+            case 9: b = BASIS_9; break;
+            case 4: b = BASIS_4; break;
+            default: b = BASIS_1; break;
+        }
+    }
+#define VR_LAUNCH(B) \
+    hipLaunchKernelGGL((render_kernel<FMA, B, N2, LOBES>), grid, block, 0, s, p)
+    switch (b) {
+        case BASIS_RGBA: VR_LAUNCH(BASIS_RGBA); break;
+        case BASIS_25: VR_LAUNCH(BASIS_25); break;
+        case BASIS_16: VR_LAUNCH(BASIS_16); break;
+        case BASIS_9: VR_LAUNCH(BASIS_9); break;
+        case BASIS_4: VR_LAUNCH(BASIS_4); break;
+        default: VR_LAUNCH(BASIS_1); break;
+    }
+#undef VR_LAUNCH
+    return hipGetLastError();
+}
+
+// Variant table: the fast N=2 kernels come with and without the SG/ASG lobe
+// code; the literal any-N descent (rare) always carries it.
+template <int FMA>
+hipError_t launch_fp(const KParams& p, dim3 grid, dim3 block, hipStream_t s) {
+    const bool n2 = (p.N == 2) && p.max_depth <= 23;
+    const bool lobes = p.format == VR_FORMAT_SG || p.format == VR_FORMAT_ASG;
+    if (!n2) return launch_basis<FMA, false, true>(p, grid, block, s);
+    if (lobes) return launch_basis<FMA, true, true>(p, grid, block, s);
+    return launch_basis<FMA, true, false>(p, grid, block, s);
+}
+
+}  // namespace
+
+hipError_t launch_render(const KParams& p, int fp_mode, hipStream_t stream) {
+    if (p.n_wave_blocks <= 0) return hipSuccess;
+    const dim3 block(kWave * kWavesPerBlock);
+    const dim3 grid((unsigned)((p.n_wave_blocks + kWavesPerBlock - 1) / kWavesPerBlock));
+    const hipError_t e = fp_mode == VR_FP_FMA ? launch_fp<1>(p, grid, block, stream)
+                                              : launch_fp<0>(p, grid, block, stream);
+    if (e != hipSuccess || !p.enable_probe || p.probe_disp_size <= 0) return e;
+    const int side = p.probe_disp_size + 5;
+    const dim3 pgrid((unsigned)((side * side + 255) / 256));
+    if (fp_mode == VR_FP_FMA)
+        hipLaunchKernelGGL(probe_overlay_kernel<1>, pgrid, dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(probe_overlay_kernel<0>, pgrid, dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble(uint8_t* frame, int64_t pitch, const uint8_t* gathered, int width,
+                           int height, int tile_w, int tile_h, int world, hipStream_t stream) {
+    const int tiles_x = (width + tile_w - 1) / tile_w, tiles_y = (height + tile_h - 1) / tile_h;
+    const int64_t n_tiles = (int64_t)tiles_x * tiles_y;
+    const int64_t tiles_per_rank = (n_tiles + world - 1) / world;
+    const dim3 block(64, 4);
+    const dim3 grid((width + 63) / 64, (height + 3) / 4);
+    hipLaunchKernelGGL(assemble_kernel, grid, block, 0, stream, frame, pitch, gathered, width,
+                       height, tile_w, tile_h, tiles_x, world, tiles_per_rank);
+    return hipGetLastError();
+}
+
+hipError_t launch_probe(const KParams& p, const float probe[3], float* out_dev,
+                        hipStream_t stream) {
+    hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, stream, p, probe[0], probe[1],
+                       probe[2], out_dev);
+    return hipGetLastError();
+}
+
+}  // namespace vr
