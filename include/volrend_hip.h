@@ -142,7 +142,18 @@ typedef struct VrFrame {
     int32_t rank, world;    /* world <= 1: render everything */
     int32_t fp_mode;        /* VR_FP_* */
     int32_t reserved;
+    uint64_t* counters;     /* optional device VrCounters (7 x u64, caller zeroes it):
+                               switches to the instrumented kernel flavour; NULL in
+                               production */
 } VrFrame;
+
+/* Access counters of one or more vr_render calls -- the algorithmic-bytes meter
+ * (SURVEY.md 8(d)): what the REFERENCE algorithm reads for these rays, i.e.
+ * per sample 4 bytes per child word from the root + 2 (sigma) + 2*(data_dim-1)
+ * when sigma > sigma_thresh, plus 4 per pixel written. */
+typedef struct VrCounters {
+    uint64_t rays, rays_hit_box, samples, child_reads, hit_samples, alg_bytes, early_stops;
+} VrCounters;
 
 /* ---- library / device ------------------------------------------------- */
 int vr_abi_version(void);

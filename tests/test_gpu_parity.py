@@ -156,3 +156,26 @@ def test_tile_shards_reassemble(torch_cuda):
         assert np.array_equal(frame.cpu().numpy(), rgba_ref), (world, tw, th)
         assert np.array_equal(out.cpu().numpy(), rgba_ref), (world, tw, th)
     t.free_device()
+
+
+@pytest.mark.parametrize("fmt,basis_dim", [("SH", 16), ("RGBA", 0), ("SG", 4)])
+def test_access_counters_match_oracle(torch_cuda, fmt, basis_dim):
+    """The instrumented kernel flavour (VrFrame.counters) is the algorithmic-bytes meter of
+    bench.py's roofline: it must agree with the oracle's counters to the integer, and it
+    must not change the image."""
+    torch = torch_cuda
+    from volrend_amd import _abi, api
+    tree = common.small_scene(depth=6, basis_dim=basis_dim, fmt=fmt, seed=91)
+    tr, w, h, f = common.camera_for(pose_idx=2, size=88)
+    rgba_o, acc_o, cnt_o = common.oracle_frame(tree, tr, w, h, f)
+    t = api.N3Tree.from_synth(tree)
+    cam = api.Camera(w, h, f, f)
+    cam.transform = tr
+    img = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    counters = torch.zeros(7, dtype=torch.int64, device="cuda")
+    api.launch_renderer(t, cam, api.RenderOptions(), img, None, None, True, counters=counters)
+    torch.cuda.synchronize()
+    cnt_g = dict(zip(_abi.COUNTER_FIELDS, [int(v) for v in counters.cpu().tolist()]))
+    assert cnt_g == cnt_o
+    assert np.array_equal(img.cpu().numpy(), rgba_o)
+    t.free_device()

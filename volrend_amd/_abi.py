@@ -52,7 +52,12 @@ class VrFrame(C.Structure):
     _fields_ = [("rgba", C.c_void_p), ("pitch", C.c_int64), ("depth", C.c_void_p),
                 ("accum", C.c_void_p), ("offscreen", C.c_int32), ("layout", C.c_int32),
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("rank", C.c_int32),
-                ("world", C.c_int32), ("fp_mode", C.c_int32), ("reserved", C.c_int32)]
+                ("world", C.c_int32), ("fp_mode", C.c_int32), ("reserved", C.c_int32),
+                ("counters", C.c_void_p)]
+
+
+COUNTER_FIELDS = ("rays", "rays_hit_box", "samples", "child_reads", "hit_samples", "alg_bytes",
+                  "early_stops")
 
 
 # name -> (restype, argtypes); also the list tests check against the header

@@ -325,7 +325,8 @@ class TileShard:
 
 def launch_renderer(tree: N3Tree, cam: Camera, options: RenderOptions, image, depth=None,
                     stream=None, offscreen: bool = False, *, accum=None, pitch: int = 0,
-                    shard: TileShard | None = None, fp_mode: int = _abi.FP_STRICT) -> None:
+                    shard: TileShard | None = None, fp_mode: int = _abi.FP_STRICT,
+                    counters=None) -> None:
     """Enqueue one frame on ``stream`` (asynchronous, like the reference).
 
     ``image``: device RGBA8 buffer (``torch.uint8`` [H,W,4] or a raw pointer);
@@ -341,6 +342,7 @@ def launch_renderer(tree: N3Tree, cam: Camera, options: RenderOptions, image, de
     f.accum = _ptr(accum)
     f.offscreen = 1 if offscreen else 0
     f.fp_mode = fp_mode
+    f.counters = _ptr(counters)  # device int64[7], zeroed by the caller (instrumentation)
     if shard is not None:
         f.tile_w, f.tile_h, f.rank, f.world = shard.tile_w, shard.tile_h, shard.rank, shard.world
         f.layout = _abi.LAYOUT_COMPACT if shard.compact else _abi.LAYOUT_FRAME

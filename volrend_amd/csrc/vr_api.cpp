@@ -380,6 +380,7 @@ int vr_render(vr_tree_t t, const VrCamera* cam, const VrRenderOptions* opt, cons
     k.accum = f->accum;
     k.offscreen = f->offscreen != 0;
     k.layout = f->layout;
+    k.counters = reinterpret_cast<unsigned long long*>(f->counters);
 
     HIP_TRY(vr::launch_render(k, f->fp_mode, static_cast<hipStream_t>(stream)));
     return VR_OK;

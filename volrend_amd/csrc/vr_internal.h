@@ -60,6 +60,7 @@ struct KParams {
     int32_t wblocks_per_tile;    // (tile_w/8)*(tile_h/8)
     int64_t n_wave_blocks;       // n_local_tiles * wblocks_per_tile
     uint32_t* status;            // device word: bit0 = iteration cap hit
+    unsigned long long* counters;  // optional VrCounters (7 x u64), instrumentation
 };
 
 // vr_kernels.hip

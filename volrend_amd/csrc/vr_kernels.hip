@@ -22,6 +22,16 @@ constexpr int kMaxIter = 1 << 22;  // guard against step_size <= 0 (upstream wou
 
 enum { BASIS_RGBA = -1, BASIS_1 = 1, BASIS_4 = 4, BASIS_9 = 9, BASIS_16 = 16, BASIS_25 = 25 };
 
+// Kernel flavours.  FAST is the production path: N == 2 integer descent, SH/RGBA
+// only, no instrumentation, zero scratch.  FULL adds the SG/ASG lobe code and
+// the optional access counters (VrFrame.counters); GENERIC additionally swaps in
+// the literal float descent for N != 2 (or trees deeper than 24 levels).
+enum { MODE_FAST = 0, MODE_FULL = 1, MODE_GENERIC = 2 };
+
+struct RayCounters {
+    uint32_t samples = 0, child_reads = 0, hits = 0, early = 0, entered = 0;
+};
+
 // ---------------------------------------------------------------------------
 // view-dependent basis, lumisphere.hpp:9-87 (double literals => FP64 products)
 // ---------------------------------------------------------------------------
@@ -104,7 +114,8 @@ __device__ __forceinline__ void precalc_basis(const KParams& p, const float* dir
 // ---------------------------------------------------------------------------
 // Literal float descent (any N).  pos is rewritten to leaf-local coordinates.
 template <int FMA>
-__device__ __forceinline__ int64_t query_generic(const KParams& p, float* xyz, float* cube_sz) {
+__device__ __forceinline__ int64_t query_generic(const KParams& p, float* xyz, float* cube_sz,
+                                                 int* levels) {
     using P = Policy<FMA>;
     const float fN = (float)p.N;
     const float hi = 1.f - 1e-6f;
@@ -121,10 +132,14 @@ __device__ __forceinline__ int64_t query_generic(const KParams& p, float* xyz, f
         }
         const int64_t sub_ptr = ptr + (int32_t)index;
         const int64_t skip = p.child[sub_ptr];
-        if (skip == 0) return sub_ptr;
+        if (skip == 0) {
+            *levels = guard + 1;
+            return sub_ptr;
+        }
         *cube_sz *= fN;
         ptr += skip * p.N3;
     }
+    *levels = 64;
     return ptr;  // unreachable for a validated tree
 }
 
@@ -132,7 +147,8 @@ __device__ __forceinline__ int64_t query_generic(const KParams& p, float* xyz, f
 // so the level-l digit is bit (23-l) of floor(x * 2^24) and the leaf-local
 // coordinate is fract(x * 2^(l+1)) -- same leaf, same bits, no float chain.
 // Valid while the deepest leaf has l <= 23 (checked at upload).
-__device__ __forceinline__ int64_t query_n2(const KParams& p, float* xyz, float* cube_sz) {
+__device__ __forceinline__ int64_t query_n2(const KParams& p, float* xyz, float* cube_sz,
+                                            int* levels) {
     const float hi = 1.f - 1e-6f;
     xyz[0] = vmax(vmin(xyz[0], hi), 0.f);
     xyz[1] = vmax(vmin(xyz[1], hi), 0.f);
@@ -152,6 +168,7 @@ __device__ __forceinline__ int64_t query_n2(const KParams& p, float* xyz, float*
     }
     const float cs = u2f((uint32_t)(127 + l + 1) << 23);  // 2^(l+1)
     *cube_sz = cs;
+    *levels = l + 1;
     xyz[0] = __builtin_amdgcn_fractf(xyz[0] * cs);
     xyz[1] = __builtin_amdgcn_fractf(xyz[1] * cs);
     xyz[2] = __builtin_amdgcn_fractf(xyz[2] * cs);
@@ -207,10 +224,14 @@ __device__ __forceinline__ float channel_dot(const float* basis_fn, const uint16
 // ---------------------------------------------------------------------------
 // trace_ray, rt_core.cuh:66-196
 // ---------------------------------------------------------------------------
-template <int FMA, int BASIS, bool N2, bool LOBES>
-__device__ __forceinline__ void trace_ray(const KParams& p, float* dir, const float* vdir, const float* cen,
-                          float tmax_bg, float* out) {
+template <int FMA, int BASIS, int MODE>
+__device__ __forceinline__ void trace_ray(const KParams& p, float* dir, const float* vdir,
+                                          const float* cen, float tmax_bg, float* out,
+                                          RayCounters& rc) {
     using P = Policy<FMA>;
+    constexpr bool N2 = MODE != MODE_GENERIC;
+    constexpr bool LOBES = MODE != MODE_FAST;
+    constexpr bool COUNT = MODE != MODE_FAST;
     // _get_delta_scale, rt_core.cuh:52-63
     dir[0] *= p.scale[0];
     dir[1] *= p.scale[1];
@@ -243,6 +264,7 @@ __device__ __forceinline__ void trace_ray(const KParams& p, float* dir, const fl
         return;
     }
 
+    if (COUNT) rc.entered++;
     float basis_fn[VR_MAX_BASIS];
 #pragma unroll
     for (int i = 0; i < VR_MAX_BASIS; ++i) basis_fn[i] = 0.f;
@@ -265,13 +287,20 @@ __device__ __forceinline__ void trace_ray(const KParams& p, float* dir, const fl
         pos[2] = P::madd(t, dir[2], cen[2]);
 
         float cube_sz;
-        const int64_t leaf = N2 ? query_n2(p, pos, &cube_sz) : query_generic<FMA>(p, pos, &cube_sz);
+        int levels;
+        const int64_t leaf = N2 ? query_n2(p, pos, &cube_sz, &levels)
+                                : query_generic<FMA>(p, pos, &cube_sz, &levels);
         const uint16_t* v = p.data + leaf * data_dim;
+        if (COUNT) {
+            rc.samples++;
+            rc.child_reads += (uint32_t)levels;
+        }
 
         const float t_subcube = dda_unit<FMA>(pos, invdir) / cube_sz;
         const float delta_t = t_subcube + p.step_size;
         const float sigma = h2f(v[data_dim - 1]);
         if (sigma > p.sigma_thresh) {
+            if (COUNT) rc.hits++;
             const float att = vr_expf(-delta_t * delta_scale * sigma);
             const float weight = light * (1.f - att);
             if (p.render_depth) {
@@ -294,6 +323,7 @@ __device__ __forceinline__ void trace_ray(const KParams& p, float* dir, const fl
                 out[1] *= scale;
                 out[2] *= scale;
                 out[3] = 1.f;
+                if (COUNT) rc.early++;
                 return;
             }
         }
@@ -323,7 +353,7 @@ __device__ __forceinline__ uint32_t quant8(float v) {
 // ---------------------------------------------------------------------------
 // render_kernel, volrend.cu:78-173.  One wave = one 8x8 pixel block.
 // ---------------------------------------------------------------------------
-template <int FMA, int BASIS, bool N2, bool LOBES>
+template <int FMA, int BASIS, int MODE>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void render_kernel(const KParams p) {
     using P = Policy<FMA>;
     const int lane = threadIdx.x & (kWave - 1);
@@ -396,7 +426,25 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void render_kernel(const KPa
                 vdir[i] = (float)P::dmadd(kd, om, (double)a);
             }
         }
-        trace_ray<FMA, BASIS, N2, LOBES>(p, dir, vdir, cen, t_max, out);
+        RayCounters rc;
+        trace_ray<FMA, BASIS, MODE>(p, dir, vdir, cen, t_max, out, rc);
+        if (MODE != MODE_FAST && p.counters) {
+            // VrCounters layout: rays, rays_hit_box, samples, child_reads, hit_samples,
+            // alg_bytes, early_stops.  alg_bytes per SURVEY.md 8(d):
+            //   sum over samples (4*L + 2 + hit*2*(data_dim-1)) + 4 per pixel
+            const unsigned long long bytes =
+                4ull * rc.child_reads + 2ull * rc.samples +
+                2ull * (unsigned long long)(p.data_dim - 1) * rc.hits + 4ull;
+            atomicAdd(&p.counters[0], 1ull);
+            atomicAdd(&p.counters[1], (unsigned long long)rc.entered);
+            atomicAdd(&p.counters[2], (unsigned long long)rc.samples);
+            atomicAdd(&p.counters[3], (unsigned long long)rc.child_reads);
+            atomicAdd(&p.counters[4], (unsigned long long)rc.hits);
+            atomicAdd(&p.counters[5], bytes);
+            atomicAdd(&p.counters[6], (unsigned long long)rc.early);
+        }
+    } else if (MODE != MODE_FAST && p.counters) {
+        atomicAdd(&p.counters[5], 4ull);
     }
     if (p.accum) {
         float4 a = make_float4(out[0], out[1], out[2], out[3]);
@@ -485,7 +533,8 @@ __global__ void probe_kernel(const KParams p, float probe0, float probe1, float 
     float cen[3] = {p.offset[0] + p.scale[0] * probe0, p.offset[1] + p.scale[1] * probe1,
                     p.offset[2] + p.scale[2] * probe2};
     float cube_sz;
-    const int64_t leaf = query_generic<0>(p, cen, &cube_sz);
+    int levels;
+    const int64_t leaf = query_generic<0>(p, cen, &cube_sz, &levels);
     const uint16_t* v = p.data + leaf * p.data_dim;
     for (int i = threadIdx.x; i < p.data_dim - 1; i += blockDim.x) out[i] = h2f(v[i]);
 }
@@ -507,7 +556,7 @@ __global__ void assemble_kernel(uint8_t* frame, int64_t pitch, const uint8_t* ga
         reinterpret_cast<const uint32_t*>(gathered)[src];
 }
 
-template <int FMA, bool N2, bool LOBES>
+template <int FMA, int MODE>
 hipError_t launch_basis(const KParams& p, dim3 grid, dim3 block, hipStream_t s) {
     int b;
     if (p.basis_dim < 0 || p.format == VR_FORMAT_RGBA) {
@@ -521,8 +570,7 @@ hipError_t launch_basis(const KParams& p, dim3 grid, dim3 block, hipStream_t s) 
             default: b = BASIS_1; break;
         }
     }
-#define VR_LAUNCH(B) \
-    hipLaunchKernelGGL((render_kernel<FMA, B, N2, LOBES>), grid, block, 0, s, p)
+#define VR_LAUNCH(B) hipLaunchKernelGGL((render_kernel<FMA, B, MODE>), grid, block, 0, s, p)
     switch (b) {
         case BASIS_RGBA: VR_LAUNCH(BASIS_RGBA); break;
         case BASIS_25: VR_LAUNCH(BASIS_25); break;
@@ -535,15 +583,13 @@ hipError_t launch_basis(const KParams& p, dim3 grid, dim3 block, hipStream_t s) 
     return hipGetLastError();
 }
 
-// Variant table: the fast N=2 kernels come with and without the SG/ASG lobe
-// code; the literal any-N descent (rare) always carries it.
 template <int FMA>
 hipError_t launch_fp(const KParams& p, dim3 grid, dim3 block, hipStream_t s) {
     const bool n2 = (p.N == 2) && p.max_depth <= 23;
     const bool lobes = p.format == VR_FORMAT_SG || p.format == VR_FORMAT_ASG;
-    if (!n2) return launch_basis<FMA, false, true>(p, grid, block, s);
-    if (lobes) return launch_basis<FMA, true, true>(p, grid, block, s);
-    return launch_basis<FMA, true, false>(p, grid, block, s);
+    if (!n2) return launch_basis<FMA, MODE_GENERIC>(p, grid, block, s);
+    if (lobes || p.counters) return launch_basis<FMA, MODE_FULL>(p, grid, block, s);
+    return launch_basis<FMA, MODE_FAST>(p, grid, block, s);
 }
 
 }  // namespace

@@ -25,15 +25,18 @@ SH_C0 = 0.28209479177387814
 
 # the five configurations, restated on synthetic inputs.
 CONFIGS = {
-    # id: depth (finest leaves = 2**depth per axis), basis, seed, image, focal, sigma range
+    # depth: finest leaves = 2**depth per axis; shell = half-thickness of the occupied
+    # surface shell in finest-leaf widths; shape_size = primitive radius range (world units).
+    # Shell / shape sizes are tuned so the node counts land on BASELINE.md's targets
+    # (C1 ~2 M nodes ~1.5 GB like the real lego tree; C0 under the 171 k-node texture limit).
     "C0": dict(depth=7, fmt="SH", basis_dim=16, seed=1001, width=400, height=400, focal=555.5556,
-               sigma=(5.0, 200.0), n_shapes=12),
+               sigma=(5.0, 200.0), n_shapes=12, shape_size=(0.5, 1.0), shell_leaves=2.0),
     "C1": dict(depth=9, fmt="SH", basis_dim=16, seed=1002, width=800, height=800, focal=1111.111,
-               sigma=(5.0, 200.0), n_shapes=12),
+               sigma=(5.0, 200.0), n_shapes=12, shape_size=(0.5, 1.0), shell_leaves=7.5),
     "C2": dict(depth=9, fmt="SH", basis_dim=25, seed=1003, width=800, height=800, focal=1111.111,
-               sigma=(1.0, 10.0), n_shapes=12),
+               sigma=(1.0, 10.0), n_shapes=12, shape_size=(0.5, 1.0), shell_leaves=7.5),
     "C3": dict(depth=10, fmt="SH", basis_dim=9, seed=1004, width=1920, height=1080, focal=1166.0,
-               sigma=(5.0, 200.0), n_shapes=12),
+               sigma=(5.0, 200.0), n_shapes=12, shape_size=(0.5, 1.0), shell_leaves=4.0),
 }
 
 
@@ -234,7 +237,9 @@ def make_config_tree(name: str, **overrides) -> SynthTree:
     cfg = dict(CONFIGS[name])
     cfg.update(overrides)
     t = make_tree(cfg["depth"], cfg["basis_dim"], cfg["fmt"], cfg["seed"], cfg["n_shapes"],
-                  cfg["sigma"], shape_size=cfg.get("shape_size", (0.25, 0.6)))
+                  cfg["sigma"], shape_size=cfg.get("shape_size", (0.25, 0.6)),
+                  shell_leaves=cfg.get("shell_leaves", 2.0),
+                  topology_only=cfg.get("topology_only", False))
     t.meta.update(config=name)
     return t
 
