@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -38,8 +39,11 @@ int fail(int code, const char* fmt, ...) {
 
 struct VrTreeOpaque {
     int device = 0;
-    int32_t* child = nullptr;
-    uint16_t* data = nullptr;
+    uint32_t* nodes = nullptr;   // device layout (vr_kernels.hip)
+    uint16_t* leaves = nullptr;
+    uint32_t* grid = nullptr;
+    int grid_levels = 0;
+    int leaf_stride_h = 0;
     float* extra = nullptr;
     uint32_t* status = nullptr;
     float* probe_buf = nullptr;  // data_dim floats: the lumisphere at opt.probe
@@ -108,10 +112,10 @@ float host_norm3(const float* d, int fma) {
 }
 
 void fill_tree_params(vr::KParams& k, const VrTreeOpaque* t) {
-    k.child = t->child;
-    k.data = t->data;
-    k.nodes = nullptr;
-    k.leaves = nullptr;
+    k.nodes = t->nodes;
+    k.leaves = t->leaves;
+    k.grid = t->grid;
+    k.grid_levels = t->grid_levels;
     k.extra = t->extra;
     for (int i = 0; i < 3; ++i) {
         k.offset[i] = t->desc.offset[i];
@@ -122,7 +126,7 @@ void fill_tree_params(vr::KParams& k, const VrTreeOpaque* t) {
     k.data_dim = t->desc.data_dim;
     k.format = t->desc.format;
     k.basis_dim = t->desc.basis_dim;
-    k.leaf_stride_h = t->desc.data_dim;
+    k.leaf_stride_h = t->leaf_stride_h;
     k.max_depth = t->max_depth;
     k.ndc_width = t->desc.ndc_width;
     k.ndc_height = t->desc.ndc_height;
@@ -219,17 +223,55 @@ int vr_tree_upload(const VrTreeDesc* d, vr_tree_t* out) {
     t->desc.extra = nullptr;
     t->max_depth = max_depth;
     hipError_t e = hipGetDevice(&t->device);
-    const hipMemcpyKind kind = d->memory == 1 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (e == hipSuccess) e = hipMalloc((void**)&t->child, child_sz);
-    if (e == hipSuccess) e = hipMalloc((void**)&t->data, data_sz);
+    // Stage the reference arrays on the device (unless they already are there),
+    // re-layout into nodes/leaves, build the restart grid, drop the staging copy.
+    int32_t* d_child = nullptr;
+    uint16_t* d_data = nullptr;
+    const int32_t* src_child = d->child;
+    const uint16_t* src_data = d->data;
+    if (d->memory != 1) {
+        if (e == hipSuccess) e = hipMalloc((void**)&d_child, child_sz);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_data, data_sz);
+        if (e == hipSuccess) e = hipMemcpy(d_child, d->child, child_sz, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_data, d->data, data_sz, hipMemcpyHostToDevice);
+        src_child = d_child;
+        src_data = d_data;
+    }
+    t->leaf_stride_h = vr::leaf_stride_halfs(d->data_dim);
+    const size_t leaves_sz = n_slots * (size_t)t->leaf_stride_h * sizeof(uint16_t);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->nodes, child_sz);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->leaves, leaves_sz);
     if (e == hipSuccess) e = hipMalloc((void**)&t->status, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(t->status, 0, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&t->probe_buf, sizeof(float) * (size_t)d->data_dim);
-    if (e == hipSuccess) e = hipMemcpy(t->child, d->child, child_sz, kind);
-    if (e == hipSuccess) e = hipMemcpy(t->data, d->data, data_sz, kind);
-    t->device_bytes = child_sz + data_sz + sizeof(uint32_t);
+    if (e == hipSuccess)
+        e = vr::launch_relayout(src_child, src_data, t->nodes, t->leaves, (int64_t)n_slots, N3,
+                                d->data_dim, t->leaf_stride_h, nullptr);
+    t->device_bytes = child_sz + leaves_sz + sizeof(uint32_t);
+    // restart grid: N == 2 only, node ids must fit the packed entry
+    t->grid_levels = 0;
+    if (e == hipSuccess && d->N == 2 && max_depth <= 23 && d->capacity < (1ll << 27)) {
+        int G = 7;
+        if (const char* env = getenv("VR_GRID_LEVELS")) G = atoi(env);
+        if (G > max_depth) G = max_depth;
+        if (G > 8) G = 8;
+        if (G >= 2) {
+            const size_t gsz = ((size_t)1 << (3 * G)) * sizeof(uint32_t);
+            e = hipMalloc((void**)&t->grid, gsz);
+            if (e == hipSuccess) e = vr::launch_build_grid(t->nodes, t->grid, G, nullptr);
+            if (e == hipSuccess) {
+                t->grid_levels = G;
+                t->device_bytes += gsz;
+            }
+        }
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (d_child) (void)hipFree(d_child);
+    if (d_data) (void)hipFree(d_data);
     if (e == hipSuccess && d->extra && d->extra_count) {
         const size_t esz = (size_t)d->extra_count * sizeof(float);
+        const hipMemcpyKind kind =
+            d->memory == 1 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
         e = hipMalloc((void**)&t->extra, esz);
         if (e == hipSuccess) e = hipMemcpy(t->extra, d->extra, esz, kind);
         t->device_bytes += esz;
@@ -245,8 +287,9 @@ int vr_tree_upload(const VrTreeDesc* d, vr_tree_t* out) {
 
 int vr_tree_free(vr_tree_t t) {
     if (!t) return VR_OK;
-    if (t->child) (void)hipFree(t->child);
-    if (t->data) (void)hipFree(t->data);
+    if (t->nodes) (void)hipFree(t->nodes);
+    if (t->leaves) (void)hipFree(t->leaves);
+    if (t->grid) (void)hipFree(t->grid);
     if (t->extra) (void)hipFree(t->extra);
     if (t->status) (void)hipFree(t->status);
     if (t->probe_buf) (void)hipFree(t->probe_buf);
@@ -264,7 +307,7 @@ int vr_tree_info(vr_tree_t t, VrTreeInfo* info) {
     info->max_depth = t->max_depth;
     info->device = t->device;
     info->device_bytes = t->device_bytes;
-    info->leaf_stride = (uint64_t)t->desc.data_dim * 2u;
+    info->leaf_stride = (uint64_t)t->leaf_stride_h * 2u;
     return VR_OK;
 }
 
@@ -381,6 +424,13 @@ int vr_render(vr_tree_t t, const VrCamera* cam, const VrRenderOptions* opt, cons
     k.offscreen = f->offscreen != 0;
     k.layout = f->layout;
     k.counters = reinterpret_cast<unsigned long long*>(f->counters);
+    {
+        const char* env = getenv("VR_XCD_REMAP");
+        k.xcd_remap = env ? atoi(env) : 0;
+        const char* mm = getenv("VR_MARCH_MAX");
+        k.march_max = mm ? atoi(mm) : 2;
+        if (k.march_max < 1) k.march_max = 1;
+    }
 
     HIP_TRY(vr::launch_render(k, f->fp_mode, static_cast<hipStream_t>(stream)));
     return VR_OK;

@@ -14,10 +14,9 @@ namespace vr {
 // here the pose rides in the argument block, so a frame is exactly one launch).
 struct KParams {
     // ---- tree (TreeSpec, data_spec.hpp:23-50) ----
-    const int32_t* child;     // reference layout [cap*N3]
-    const uint16_t* data;     // reference layout [cap*N3*data_dim] fp16 bits
-    const uint32_t* nodes;    // device re-layout: per child slot, see vr_kernels.hip
-    const uint16_t* leaves;   // device re-layout: padded SH records
+    const uint32_t* nodes;    // device layout: one word per child slot (vr_kernels.hip)
+    const uint16_t* leaves;   // device layout: padded coefficient records
+    const uint32_t* grid;     // device layout: top-level restart grid (N == 2) or NULL
     const float* extra;
     float offset[3];
     float scale[3];
@@ -27,6 +26,9 @@ struct KParams {
     int32_t basis_dim;
     int32_t leaf_stride_h;    // fp16 elements between padded records
     int32_t max_depth;        // deepest leaf level (child words read - 1)
+    int32_t grid_levels;      // G: grid has 2^G cells per axis (0 = no grid)
+    int32_t xcd_remap;        // 1: contiguous wave-block range per XCD
+    int32_t march_max;        // empty-space steps per lane between two shade phases
     float ndc_width, ndc_height, ndc_focal;
     // ---- camera (CameraSpec, data_spec.hpp:11-22) ----
     float xf[12];
@@ -69,5 +71,11 @@ hipError_t launch_assemble(uint8_t* frame, int64_t pitch, const uint8_t* gathere
                            int height, int tile_w, int tile_h, int world, hipStream_t stream);
 hipError_t launch_probe(const KParams& p, const float probe[3], float* out_dev,
                         hipStream_t stream);
+// upload-time re-layout of the reference arrays into the device layout
+int leaf_stride_halfs(int data_dim);
+hipError_t launch_relayout(const int32_t* child, const uint16_t* data, uint32_t* nodes,
+                           uint16_t* leaves, int64_t n_slots, int N3, int data_dim, int stride_h,
+                           hipStream_t stream);
+hipError_t launch_build_grid(const uint32_t* nodes, uint32_t* grid, int G, hipStream_t stream);
 
 }  // namespace vr

@@ -4,8 +4,10 @@
 // (src/cuda/volrend.cu:78-173) with trace_ray (include/volrend/cuda/rt_core.cuh:66-196),
 // query_single_from_root (include/volrend/internal/n3tree_query.hpp:13-48) and
 // maybe_precalc_basis (include/volrend/internal/lumisphere.hpp:9-87) -- written
-// from the algorithm, not from the CUDA text: wave64 8x8 pixel tiles, integer
-// digit descent for N=2 (bit-identical to the float descent, see query_n2),
+// from the algorithm, not from the CUDA text: wave64 8x8 pixel tiles, a device
+// re-layout built at upload (sigma packed into the node words, padded 16-byte
+// aligned SH records, a top-level restart grid), integer digit descent for N=2
+// (bit-identical to the float descent, see query_n2), march/shade phase split,
 // deterministic expf, explicit FP contraction policy.
 //
 // Built with -ffp-contract=off; see vr_device_math.h.
@@ -110,45 +112,74 @@ __device__ __forceinline__ void precalc_basis(const KParams& p, const float* dir
 }
 
 // ---------------------------------------------------------------------------
-// octree point query, n3tree_query.hpp:13-48
+// Device layout (built once at upload by the relayout kernels below; the
+// tree.npz format and the reference's flat child_/data_ arrays are the INPUT):
+//
+//   nodes[capacity*N3]   one 32-bit word per child slot
+//        bit31 = 0 : internal -- ABSOLUTE index of the child node (> 0)
+//        bit31 = 1 : leaf     -- low 16 bits = sigma as IEEE fp16
+//     so the descent's last load already delivers sigma: an empty-space
+//     sample never touches the (GB-sized) coefficient array.
+//   leaves[capacity*N3*stride] the data_dim-1 colour coefficients of each slot,
+//     fp16, zero padded to `stride` bytes (16-byte aligned; 128 B = one cache
+//     line for SH16) so a record is read with a few aligned 16-byte loads.
+//   grid[8^G]            (N == 2) for every cell of the 2^G-per-axis grid the
+//     deepest node at level <= G containing it: (level << 27) | node.  A sample
+//     whose previous parent node does not contain it restarts here instead of
+//     at the root -- same leaf, same bits, ~3x fewer dependent loads.
 // ---------------------------------------------------------------------------
-// Literal float descent (any N).  pos is rewritten to leaf-local coordinates.
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr int kGridNodeBits = 27;
+
+// octree point query, n3tree_query.hpp:13-48 -- literal float descent (any N).
+// xyz is rewritten to leaf-local coordinates; returns the leaf slot index.
 template <int FMA>
 __device__ __forceinline__ int64_t query_generic(const KParams& p, float* xyz, float* cube_sz,
-                                                 int* levels) {
+                                                 int* levels, uint32_t* word) {
     using P = Policy<FMA>;
     const float fN = (float)p.N;
     const float hi = 1.f - 1e-6f;
+#pragma unroll
     for (int i = 0; i < 3; ++i) xyz[i] = vmax(vmin(xyz[i], hi), 0.f);
-    int64_t ptr = 0;
+    int64_t node = 0;
     *cube_sz = fN;
-    for (int guard = 0; guard < 64; ++guard) {
+    int64_t sub_ptr = 0;
+    uint32_t w = kLeafBit;
+    int l = 0;
+    for (; l < 64; ++l) {
         float index = 0.f;
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
             xyz[i] *= fN;
             const float k = __builtin_floorf(xyz[i]);
             index = P::madd(index, fN, k);
             xyz[i] -= k;
         }
-        const int64_t sub_ptr = ptr + (int32_t)index;
-        const int64_t skip = p.child[sub_ptr];
-        if (skip == 0) {
-            *levels = guard + 1;
-            return sub_ptr;
-        }
+        sub_ptr = node * p.N3 + (int32_t)index;
+        w = p.nodes[sub_ptr];
+        if (w & kLeafBit) break;
         *cube_sz *= fN;
-        ptr += skip * p.N3;
+        node = (int64_t)w;
     }
-    *levels = 64;
-    return ptr;  // unreachable for a validated tree
+    *levels = l + 1;
+    *word = w;
+    return sub_ptr;
 }
 
-// N == 2: the float recurrence {x*=2; k=floor(x); x-=k} is exact in binary32,
-// so the level-l digit is bit (23-l) of floor(x * 2^24) and the leaf-local
+// Per-lane traversal cache for the N == 2 integer descent.
+struct Cursor {
+    uint32_t ux = 0, uy = 0, uz = 0;  // 24-bit cell coordinates of the previous sample
+    uint32_t node = 0;                // node that contained the previous leaf
+    int level = 0;                    // its level (0 = root, which contains everything)
+};
+
+// N == 2: the float recurrence {x*=2; k=floor(x); x-=k} is exact in binary32, so
+// the level-l digit is bit (23-l) of floor(x * 2^24) and the leaf-local
 // coordinate is fract(x * 2^(l+1)) -- same leaf, same bits, no float chain.
 // Valid while the deepest leaf has l <= 23 (checked at upload).
-__device__ __forceinline__ int64_t query_n2(const KParams& p, float* xyz, float* cube_sz,
-                                            int* levels) {
+template <bool USE_GRID>
+__device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, float* cube_sz,
+                                             int* levels, uint32_t* word, Cursor& cur) {
     const float hi = 1.f - 1e-6f;
     xyz[0] = vmax(vmin(xyz[0], hi), 0.f);
     xyz[1] = vmax(vmin(xyz[1], hi), 0.f);
@@ -156,23 +187,44 @@ __device__ __forceinline__ int64_t query_n2(const KParams& p, float* xyz, float*
     const uint32_t ux = (uint32_t)(xyz[0] * 16777216.f);
     const uint32_t uy = (uint32_t)(xyz[1] * 16777216.f);
     const uint32_t uz = (uint32_t)(xyz[2] * 16777216.f);
-    uint32_t node = 0;
-    int l = 0;
-    uint32_t slot;
+    uint32_t node;
+    int l;
+    // does the node that held the previous leaf still contain this point?
+    const uint32_t diff = (ux ^ cur.ux) | (uy ^ cur.uy) | (uz ^ cur.uz);
+    if ((diff >> (24 - cur.level)) == 0u || cur.level == 0) {
+        node = cur.node;
+        l = cur.level;
+    } else if (USE_GRID && p.grid_levels > 0) {
+        const int g = p.grid_levels, sh = 24 - g;
+        const uint32_t cell = ((ux >> sh) << (2 * g)) | ((uy >> sh) << g) | (uz >> sh);
+        const uint32_t e = p.grid[cell];
+        node = e & ((1u << kGridNodeBits) - 1u);
+        l = (int)(e >> kGridNodeBits);
+    } else {
+        node = 0;
+        l = 0;
+    }
+    uint32_t slot, w;
     for (;; ++l) {
         const int sh = 23 - l;
         slot = (((ux >> sh) & 1u) << 2) | (((uy >> sh) & 1u) << 1) | ((uz >> sh) & 1u);
-        const int32_t skip = p.child[(uint64_t)node * 8u + slot];
-        if (skip == 0 || l >= 23) break;
-        node += (uint32_t)skip;
+        w = p.nodes[(uint64_t)node * 8u + slot];
+        if ((w & kLeafBit) || l >= 23) break;
+        node = w;
     }
+    cur.ux = ux;
+    cur.uy = uy;
+    cur.uz = uz;
+    cur.node = node;
+    cur.level = l;
     const float cs = u2f((uint32_t)(127 + l + 1) << 23);  // 2^(l+1)
     *cube_sz = cs;
     *levels = l + 1;
+    *word = w;
     xyz[0] = __builtin_amdgcn_fractf(xyz[0] * cs);
     xyz[1] = __builtin_amdgcn_fractf(xyz[1] * cs);
     xyz[2] = __builtin_amdgcn_fractf(xyz[2] * cs);
-    return (int64_t)node * 8 + slot;
+    return node * 8u + slot;
 }
 
 // rt_core.cuh:37-49
@@ -189,156 +241,85 @@ __device__ __forceinline__ float dda_unit(const float* cen, const float* invdir)
     return tmax;
 }
 
-// SH / SG colour of one channel: rt_core.cuh:125-165.  Group order 25 -> 16 -> 9
+// ---------------------------------------------------------------------------
+// One leaf record in registers.  NV = 16-byte vectors per record for the
+// compile-time basis sizes; BASIS_1 / RGBA use narrower loads.
+// ---------------------------------------------------------------------------
+template <int BASIS>
+struct RecTraits {
+    static constexpr int kHalfs = BASIS > 1 ? 3 * BASIS : 3;
+    static constexpr int kDwords = BASIS > 1 ? ((kHalfs * 2 + 15) / 16) * 4 : 2;
+};
+
+template <int BASIS>
+struct Record {
+    uint32_t w[RecTraits<BASIS>::kDwords];
+    // coefficient i (compile-time) as fp32
+    __device__ __forceinline__ float at(int i) const {
+        const uint32_t d = w[i >> 1];
+        return h2f((uint16_t)((i & 1) ? (d >> 16) : (d & 0xFFFFu)));
+    }
+};
+
+template <int BASIS>
+__device__ __forceinline__ void load_record(const KParams& p, uint32_t leaf, Record<BASIS>& r) {
+    const uint16_t* base = p.leaves + (uint64_t)leaf * (uint32_t)p.leaf_stride_h;
+    if (BASIS == BASIS_RGBA) {
+        const uint2 v = *reinterpret_cast<const uint2*>(base);  // stride >= 8 B
+        r.w[0] = v.x;
+        r.w[1] = v.y;
+    } else if (BASIS == BASIS_1) {
+        // runtime channel stride (basis_dim is not one of 4/9/16/25): only the
+        // first coefficient of each channel is used, rt_core.cuh:131
+        const uint32_t c0 = base[0], c1 = base[p.basis_dim], c2 = base[2 * p.basis_dim];
+        r.w[0] = c0 | (c1 << 16);
+        r.w[1] = c2;
+    } else {
+        const uint4* v = reinterpret_cast<const uint4*>(base);
+#pragma unroll
+        for (int j = 0; j < RecTraits<BASIS>::kDwords / 4; ++j) {
+            const uint4 q = v[j];
+            r.w[4 * j + 0] = q.x;
+            r.w[4 * j + 1] = q.y;
+            r.w[4 * j + 2] = q.z;
+            r.w[4 * j + 3] = q.w;
+        }
+    }
+}
+
+// SH / SG colour of channel c: rt_core.cuh:125-165.  Group order 25 -> 16 -> 9
 // -> 4, each group summed left to right, then added to tmp.
 template <int FMA, int BASIS>
-__device__ __forceinline__ float channel_dot(const float* basis_fn, const uint16_t* v) {
+__device__ __forceinline__ float channel_dot(const float* basis_fn, const Record<BASIS>& r,
+                                             int c) {
     using P = Policy<FMA>;
-    float tmp = basis_fn[0] * h2f(v[0]);
+    if (BASIS == BASIS_1) return basis_fn[0] * r.at(c);
+    const int o = c * BASIS;
+    float tmp = basis_fn[0] * r.at(o);
     if (BASIS == 25) {
-        float g = P::madd(basis_fn[16], h2f(v[16]), basis_fn[17] * h2f(v[17]));
+        float g = P::madd(basis_fn[16], r.at(o + 16), basis_fn[17] * r.at(o + 17));
 #pragma unroll
-        for (int i = 18; i <= 24; ++i) g = P::madd(basis_fn[i], h2f(v[i]), g);
+        for (int i = 18; i <= 24; ++i) g = P::madd(basis_fn[i], r.at(o + i), g);
         tmp += g;
     }
     if (BASIS >= 16) {
-        float g = P::madd(basis_fn[9], h2f(v[9]), basis_fn[10] * h2f(v[10]));
+        float g = P::madd(basis_fn[9], r.at(o + 9), basis_fn[10] * r.at(o + 10));
 #pragma unroll
-        for (int i = 11; i <= 15; ++i) g = P::madd(basis_fn[i], h2f(v[i]), g);
+        for (int i = 11; i <= 15; ++i) g = P::madd(basis_fn[i], r.at(o + i), g);
         tmp += g;
     }
     if (BASIS >= 9) {
-        float g = P::madd(basis_fn[4], h2f(v[4]), basis_fn[5] * h2f(v[5]));
+        float g = P::madd(basis_fn[4], r.at(o + 4), basis_fn[5] * r.at(o + 5));
 #pragma unroll
-        for (int i = 6; i <= 8; ++i) g = P::madd(basis_fn[i], h2f(v[i]), g);
+        for (int i = 6; i <= 8; ++i) g = P::madd(basis_fn[i], r.at(o + i), g);
         tmp += g;
     }
     if (BASIS >= 4) {
-        float g = P::madd(basis_fn[1], h2f(v[1]), basis_fn[2] * h2f(v[2]));
-        g = P::madd(basis_fn[3], h2f(v[3]), g);
+        float g = P::madd(basis_fn[1], r.at(o + 1), basis_fn[2] * r.at(o + 2));
+        g = P::madd(basis_fn[3], r.at(o + 3), g);
         tmp += g;
     }
     return tmp;
-}
-
-// ---------------------------------------------------------------------------
-// trace_ray, rt_core.cuh:66-196
-// ---------------------------------------------------------------------------
-template <int FMA, int BASIS, int MODE>
-__device__ __forceinline__ void trace_ray(const KParams& p, float* dir, const float* vdir,
-                                          const float* cen, float tmax_bg, float* out,
-                                          RayCounters& rc) {
-    using P = Policy<FMA>;
-    constexpr bool N2 = MODE != MODE_GENERIC;
-    constexpr bool LOBES = MODE != MODE_FAST;
-    constexpr bool COUNT = MODE != MODE_FAST;
-    // _get_delta_scale, rt_core.cuh:52-63
-    dir[0] *= p.scale[0];
-    dir[1] *= p.scale[1];
-    dir[2] *= p.scale[2];
-    const float delta_scale = 1.f / norm3<FMA>(dir);
-    dir[0] *= delta_scale;
-    dir[1] *= delta_scale;
-    dir[2] *= delta_scale;
-    tmax_bg /= delta_scale;
-
-    float invdir[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) invdir[i] = (float)(1.0 / ((double)dir[i] + 1e-9));
-
-    // _dda_world, rt_core.cuh:18-34: the 1e-6 literals make this FP64
-    float tmin = 0.0f, tmax = 1e4f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float t1 =
-            (float)((((double)p.bbox[i] + 1e-6) - (double)cen[i]) * (double)invdir[i]);
-        const float t2 =
-            (float)((((double)p.bbox[i + 3] - 1e-6) - (double)cen[i]) * (double)invdir[i]);
-        tmin = vmax(tmin, vmin(t1, t2));
-        tmax = vmin(tmax, vmax(t1, t2));
-    }
-    tmax = vmin(tmax, tmax_bg);
-
-    if (tmax < 0 || tmin > tmax) {
-        if (p.render_depth) out[3] = 1.f;
-        return;
-    }
-
-    if (COUNT) rc.entered++;
-    float basis_fn[VR_MAX_BASIS];
-#pragma unroll
-    for (int i = 0; i < VR_MAX_BASIS; ++i) basis_fn[i] = 0.f;
-    if (BASIS != BASIS_RGBA) {
-        precalc_basis<FMA, LOBES>(p, vdir, basis_fn);
-#pragma unroll
-        for (int i = 0; i < VR_MAX_BASIS; ++i)
-            if (i < p.basis_min || i > p.basis_max) basis_fn[i] = 0.f;
-    }
-
-    const int data_dim = p.data_dim;
-    const int bstride = p.basis_dim;
-    float light = 1.f;
-    float t = tmin;
-    int iter = 0;
-    while (t < tmax) {
-        float pos[3];
-        pos[0] = P::madd(t, dir[0], cen[0]);
-        pos[1] = P::madd(t, dir[1], cen[1]);
-        pos[2] = P::madd(t, dir[2], cen[2]);
-
-        float cube_sz;
-        int levels;
-        const int64_t leaf = N2 ? query_n2(p, pos, &cube_sz, &levels)
-                                : query_generic<FMA>(p, pos, &cube_sz, &levels);
-        const uint16_t* v = p.data + leaf * data_dim;
-        if (COUNT) {
-            rc.samples++;
-            rc.child_reads += (uint32_t)levels;
-        }
-
-        const float t_subcube = dda_unit<FMA>(pos, invdir) / cube_sz;
-        const float delta_t = t_subcube + p.step_size;
-        const float sigma = h2f(v[data_dim - 1]);
-        if (sigma > p.sigma_thresh) {
-            if (COUNT) rc.hits++;
-            const float att = vr_expf(-delta_t * delta_scale * sigma);
-            const float weight = light * (1.f - att);
-            if (p.render_depth) {
-                out[0] = P::madd(weight, t, out[0]);
-            } else if (BASIS != BASIS_RGBA) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float tmp = channel_dot<FMA, BASIS>(basis_fn, v + c * bstride);
-                    out[c] += weight / (1.f + vr_expf(-tmp));
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) out[c] = P::madd(h2f(v[c]), weight, out[c]);
-            }
-            light *= att;
-            if (light < p.stop_thresh) {
-                if (p.render_depth) out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
-                const float scale = 1.f / (1.f - light);
-                out[0] *= scale;
-                out[1] *= scale;
-                out[2] *= scale;
-                out[3] = 1.f;
-                if (COUNT) rc.early++;
-                return;
-            }
-        }
-        t += delta_t;
-        if (++iter >= kMaxIter) {
-            if (p.status) atomicOr(p.status, 1u);
-            break;
-        }
-    }
-    if (p.render_depth) {
-        out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
-        out[3] = 1.f;
-    } else {
-        out[3] = 1.f - light;
-    }
 }
 
 __device__ __forceinline__ uint32_t quant8(float v) {
@@ -350,14 +331,38 @@ __device__ __forceinline__ uint32_t quant8(float v) {
     return (uint32_t)(int32_t)s & 0xFFu;
 }
 
+__device__ __forceinline__ bool wave_any(bool v) { return __builtin_amdgcn_ballot_w64(v) != 0ull; }
+
 // ---------------------------------------------------------------------------
-// render_kernel, volrend.cu:78-173.  One wave = one 8x8 pixel block.
+// render_kernel: render_kernel + trace_ray of the reference
+// (volrend.cu:78-173, rt_core.cuh:66-196).  One wave = one 8x8 pixel block,
+// one lane = one ray.  The march loop is split in two wave-level phases:
+//   march : lanes step through empty space (descent + sigma test, no colour
+//           data) until each has found a sample with sigma > sigma_thresh or
+//           left the volume;
+//   shade : the lanes holding such a sample fetch the SH record, evaluate the
+//           colour and composite -- all of them together.
+// Per-ray arithmetic and its order are exactly the reference's.
 // ---------------------------------------------------------------------------
 template <int FMA, int BASIS, int MODE>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void render_kernel(const KParams p) {
     using P = Policy<FMA>;
+    constexpr bool N2 = MODE != MODE_GENERIC;
+    constexpr bool LOBES = MODE != MODE_FAST;
+    constexpr bool COUNT = MODE != MODE_FAST;
+
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t wb = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    int64_t wb = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (p.xcd_remap) {
+        // blocks are dealt round-robin to the 8 XCDs (each with a private L2): give
+        // every XCD one contiguous run of wave blocks = one screen region
+        const int64_t nb = gridDim.x;
+        const int64_t b = blockIdx.x;
+        const int64_t per = nb / 8, rem = nb % 8;
+        const int64_t xcd = b % 8, j = b / 8;
+        const int64_t logical = xcd * per + (xcd < rem ? xcd : rem) + j;
+        wb = logical * kWavesPerBlock + (threadIdx.x >> 6);
+    }
     if (wb >= p.n_wave_blocks) return;
     // wave block -> local tile -> frame tile -> pixel
     const int32_t k = (int32_t)(wb / p.wblocks_per_tile);
@@ -367,23 +372,29 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void render_kernel(const KPa
     const int32_t sy = sub / p.wblocks_per_tile_x, sx = sub - sy * p.wblocks_per_tile_x;
     const int32_t lx = sx * 8 + (lane & 7), ly = sy * 8 + (lane >> 3);  // within tile
     const int32_t x = tx * p.tile_w + lx, y = ty * p.tile_h + ly;
-    if (x >= p.width || y >= p.height) return;
+    const bool in_image = x < p.width && y < p.height;
 
-    uint8_t* px;
-    if (p.layout == VR_LAYOUT_COMPACT)
-        px = p.rgba + ((int64_t)k * p.tile_w * p.tile_h + (int64_t)ly * p.tile_w + lx) * 4;
-    else
-        px = p.rgba + (int64_t)y * p.pitch + (int64_t)x * 4;
-    const int64_t pix = (int64_t)y * p.width + x;
-
+    uint8_t* px = nullptr;
+    int64_t pix = 0;
     uint32_t init = 0;
-    if (!p.offscreen) init = *reinterpret_cast<const uint32_t*>(px);
+    if (in_image) {
+        if (p.layout == VR_LAYOUT_COMPACT)
+            px = p.rgba + ((int64_t)k * p.tile_w * p.tile_h + (int64_t)ly * p.tile_w + lx) * 4;
+        else
+            px = p.rgba + (int64_t)y * p.pitch + (int64_t)x * 4;
+        pix = (int64_t)y * p.width + x;
+        if (!p.offscreen) init = *reinterpret_cast<const uint32_t*>(px);
+    }
 
-    float dir[3], cen[3], out[4] = {0.f, 0.f, 0.f, 0.f};
     // The probe circle (volrend.cu:100-134) is drawn by probe_overlay_kernel after this
     // kernel: circle pixels end with out[3]=1, i.e. they do not depend on anything here.
-    const bool enable_draw = p.N > 0;
-    if (enable_draw) {
+    float dir[3] = {0.f, 0.f, 1.f}, cen[3] = {0.f, 0.f, 0.f}, vdir[3];
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+    float t = 0.f, tmax = -1.f, delta_scale = 1.f;
+    float invdir[3] = {1.f, 1.f, 1.f};
+    bool alive = false;    // still inside `while (t < tmax)`
+    bool entered = false;  // passed the ray/box test of rt_core.cuh:88
+    if (in_image && p.N > 0) {
         // screen2worlddir, volrend.cu:22-32 (no +0.5 pixel centre offset)
         float xyz[3];
         xyz[0] = P::nmadd(0.5f, (float)p.width, (float)x) / p.fx;
@@ -394,12 +405,14 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void render_kernel(const KPa
         cen[0] = p.xf[9];
         cen[1] = p.xf[10];
         cen[2] = p.xf[11];
-        float vdir[3] = {dir[0], dir[1], dir[2]};
+        vdir[0] = dir[0];
+        vdir[1] = dir[1];
+        vdir[2] = dir[2];
 
         if (p.ndc_width > 0) {  // maybe_world2ndc, volrend.cu:34-54
-            const float t = -(1.f + cen[2]) / dir[2];
+            const float tt = -(1.f + cen[2]) / dir[2];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) cen[i] = P::madd(t, dir[i], cen[i]);
+            for (int i = 0; i < 3; ++i) cen[i] = P::madd(tt, dir[i], cen[i]);
             dir[0] = -((2.f * p.ndc_focal) / p.ndc_width) * (dir[0] / dir[2] - cen[0] / cen[2]);
             dir[1] = -((2.f * p.ndc_focal) / p.ndc_height) * (dir[1] / dir[2] - cen[1] / cen[2]);
             dir[2] = -2.f / cen[2];
@@ -411,8 +424,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void render_kernel(const KPa
 #pragma unroll
         for (int i = 0; i < 3; ++i) cen[i] = P::madd(p.scale[i], cen[i], p.offset[i]);
 
-        float t_max = 1e9f;
-        if (!p.offscreen && p.depth) t_max = p.depth[pix];
+        float tmax_bg = 1e9f;
+        if (!p.offscreen && p.depth) tmax_bg = p.depth[pix];
 
         if (p.rot_enabled) {  // rodrigues, volrend.cu:57-71 (uniform part done on host)
             float cr[3];
@@ -426,30 +439,167 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void render_kernel(const KPa
                 vdir[i] = (float)P::dmadd(kd, om, (double)a);
             }
         }
-        RayCounters rc;
-        trace_ray<FMA, BASIS, MODE>(p, dir, vdir, cen, t_max, out, rc);
-        if (MODE != MODE_FAST && p.counters) {
-            // VrCounters layout: rays, rays_hit_box, samples, child_reads, hit_samples,
-            // alg_bytes, early_stops.  alg_bytes per SURVEY.md 8(d):
-            //   sum over samples (4*L + 2 + hit*2*(data_dim-1)) + 4 per pixel
-            const unsigned long long bytes =
-                4ull * rc.child_reads + 2ull * rc.samples +
-                2ull * (unsigned long long)(p.data_dim - 1) * rc.hits + 4ull;
-            atomicAdd(&p.counters[0], 1ull);
-            atomicAdd(&p.counters[1], (unsigned long long)rc.entered);
-            atomicAdd(&p.counters[2], (unsigned long long)rc.samples);
-            atomicAdd(&p.counters[3], (unsigned long long)rc.child_reads);
-            atomicAdd(&p.counters[4], (unsigned long long)rc.hits);
-            atomicAdd(&p.counters[5], bytes);
-            atomicAdd(&p.counters[6], (unsigned long long)rc.early);
+
+        // ---- trace_ray prologue, rt_core.cuh:74-92 ----
+        // _get_delta_scale, rt_core.cuh:52-63
+        dir[0] *= p.scale[0];
+        dir[1] *= p.scale[1];
+        dir[2] *= p.scale[2];
+        delta_scale = 1.f / norm3<FMA>(dir);
+        dir[0] *= delta_scale;
+        dir[1] *= delta_scale;
+        dir[2] *= delta_scale;
+        tmax_bg /= delta_scale;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) invdir[i] = (float)(1.0 / ((double)dir[i] + 1e-9));
+        // _dda_world, rt_core.cuh:18-34: the 1e-6 literals make this FP64
+        float tmin = 0.0f;
+        tmax = 1e4f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float t1 =
+                (float)((((double)p.bbox[i] + 1e-6) - (double)cen[i]) * (double)invdir[i]);
+            const float t2 =
+                (float)((((double)p.bbox[i + 3] - 1e-6) - (double)cen[i]) * (double)invdir[i]);
+            tmin = vmax(tmin, vmin(t1, t2));
+            tmax = vmin(tmax, vmax(t1, t2));
         }
-    } else if (MODE != MODE_FAST && p.counters) {
-        atomicAdd(&p.counters[5], 4ull);
+        tmax = vmin(tmax, tmax_bg);
+        if (tmax < 0 || tmin > tmax) {
+            if (p.render_depth) out[3] = 1.f;  // ray misses the box
+        } else {
+            entered = true;
+            t = tmin;
+            alive = t < tmax;
+        }
     }
-    if (p.accum) {
-        float4 a = make_float4(out[0], out[1], out[2], out[3]);
-        reinterpret_cast<float4*>(p.accum)[pix] = a;
+
+    RayCounters rc;
+
+    float basis_fn[VR_MAX_BASIS];
+#pragma unroll
+    for (int i = 0; i < VR_MAX_BASIS; ++i) basis_fn[i] = 0.f;
+    if (BASIS != BASIS_RGBA && wave_any(alive)) {
+        precalc_basis<FMA, LOBES>(p, vdir, basis_fn);
+#pragma unroll
+        for (int i = 0; i < VR_MAX_BASIS; ++i)
+            if (i < p.basis_min || i > p.basis_max) basis_fn[i] = 0.f;
     }
+
+    float light = 1.f;
+    bool stopped = false;  // ended by stop_thresh (out[3] already final)
+    Cursor cur;
+    int iter = 0;
+    // ---- march / shade loop, rt_core.cuh:108-188 ----
+    for (;;) {
+        bool pend = false;
+        uint32_t leaf = 0;
+        float delta_t = 0.f, sigma = 0.f;
+        // march: up to march_max steps, or until every live lane holds a sample to
+        // shade (or died)
+        for (int m = 0; m < p.march_max && wave_any(alive && !pend); ++m) {
+            if (alive && !pend) {
+                float pos[3];
+                pos[0] = P::madd(t, dir[0], cen[0]);
+                pos[1] = P::madd(t, dir[1], cen[1]);
+                pos[2] = P::madd(t, dir[2], cen[2]);
+                float cube_sz;
+                int levels;
+                uint32_t word;
+                if (N2) {
+                    leaf = query_n2<true>(p, pos, &cube_sz, &levels, &word, cur);
+                } else {
+                    leaf = (uint32_t)query_generic<FMA>(p, pos, &cube_sz, &levels, &word);
+                }
+                if (COUNT) {
+                    rc.samples++;
+                    rc.child_reads += (uint32_t)levels;
+                }
+                const float t_subcube = dda_unit<FMA>(pos, invdir) / cube_sz;
+                delta_t = t_subcube + p.step_size;
+                sigma = h2f((uint16_t)(word & 0xFFFFu));
+                if (sigma > p.sigma_thresh) {
+                    pend = true;
+                } else {
+                    t += delta_t;
+                    alive = t < tmax;
+                    if (++iter >= kMaxIter) {
+                        alive = false;
+                        if (p.status) atomicOr(p.status, 1u);
+                    }
+                }
+            }
+        }
+        if (!wave_any(pend)) {
+            if (!wave_any(alive)) break;
+            continue;
+        }
+        if (pend) {
+            if (COUNT) rc.hits++;
+            const float att = vr_expf(-delta_t * delta_scale * sigma);
+            const float weight = light * (1.f - att);
+            if (p.render_depth) {
+                out[0] = P::madd(weight, t, out[0]);
+            } else {
+                Record<BASIS> rec;
+                load_record<BASIS>(p, leaf, rec);
+                if (BASIS != BASIS_RGBA) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float tmp = channel_dot<FMA, BASIS>(basis_fn, rec, c);
+                        out[c] += weight / (1.f + vr_expf(-tmp));
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) out[c] = P::madd(rec.at(c), weight, out[c]);
+                }
+            }
+            light *= att;
+            if (light < p.stop_thresh) {
+                if (p.render_depth) out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
+                const float scale = 1.f / (1.f - light);
+                out[0] *= scale;
+                out[1] *= scale;
+                out[2] *= scale;
+                out[3] = 1.f;
+                stopped = true;
+                alive = false;
+                if (COUNT) rc.early++;
+            } else {
+                t += delta_t;
+                alive = t < tmax;
+                if (++iter >= kMaxIter) {
+                    alive = false;
+                    if (p.status) atomicOr(p.status, 1u);
+                }
+            }
+        }
+    }
+    if (!in_image) return;
+    if (entered && !stopped) {  // rt_core.cuh:189-194
+        if (p.render_depth) {
+            out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
+            out[3] = 1.f;
+        } else {
+            out[3] = 1.f - light;
+        }
+    }
+    if (COUNT && p.counters) {
+        // VrCounters: rays, rays_hit_box, samples, child_reads, hit_samples, alg_bytes,
+        // early_stops.  alg_bytes per SURVEY.md 8(d):
+        //   sum over samples (4*L + 2 + hit*2*(data_dim-1)) + 4 per pixel
+        const unsigned long long bytes = 4ull * rc.child_reads + 2ull * rc.samples +
+                                         2ull * (unsigned long long)(p.data_dim - 1) * rc.hits +
+                                         4ull;
+        if (p.N > 0) atomicAdd(&p.counters[0], 1ull);
+        atomicAdd(&p.counters[1], entered ? 1ull : 0ull);
+        atomicAdd(&p.counters[2], (unsigned long long)rc.samples);
+        atomicAdd(&p.counters[3], (unsigned long long)rc.child_reads);
+        atomicAdd(&p.counters[4], (unsigned long long)rc.hits);
+        atomicAdd(&p.counters[5], bytes);
+        atomicAdd(&p.counters[6], (unsigned long long)rc.early);
+    }
+    if (p.accum) reinterpret_cast<float4*>(p.accum)[pix] = make_float4(out[0], out[1], out[2], out[3]);
     // composite, volrend.cu:152-172
     const float nalpha = 1.f - out[3];
     if (p.offscreen) {
@@ -461,9 +611,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void render_kernel(const KPa
         out[1] = P::madd((float)((init >> 8) & 0xFFu) / 255.f, nalpha, out[1]);
         out[2] = P::madd((float)((init >> 16) & 0xFFu) / 255.f, nalpha, out[2]);
     }
-    const uint32_t rgba =
+    *reinterpret_cast<uint32_t*>(px) =
         quant8(out[0]) | (quant8(out[1]) << 8) | (quant8(out[2]) << 16) | 0xFF000000u;
-    *reinterpret_cast<uint32_t*>(px) = rgba;
 }
 
 // Probe circle overlay, volrend.cu:100-134.  Pixels inside the circle skip the
@@ -534,8 +683,9 @@ __global__ void probe_kernel(const KParams p, float probe0, float probe1, float 
                     p.offset[2] + p.scale[2] * probe2};
     float cube_sz;
     int levels;
-    const int64_t leaf = query_generic<0>(p, cen, &cube_sz, &levels);
-    const uint16_t* v = p.data + leaf * p.data_dim;
+    uint32_t word;
+    const int64_t leaf = query_generic<0>(p, cen, &cube_sz, &levels, &word);
+    const uint16_t* v = p.leaves + leaf * p.leaf_stride_h;
     for (int i = threadIdx.x; i < p.data_dim - 1; i += blockDim.x) out[i] = h2f(v[i]);
 }
 
@@ -554,6 +704,65 @@ __global__ void assemble_kernel(uint8_t* frame, int64_t pitch, const uint8_t* ga
     const int64_t src = ((rank * tiles_per_rank + k) * tile_w * tile_h + (int64_t)ly * tile_w + lx);
     *reinterpret_cast<uint32_t*>(frame + (int64_t)y * pitch + (int64_t)x * 4) =
         reinterpret_cast<const uint32_t*>(gathered)[src];
+}
+
+// ---------------------------------------------------------------------------
+// Upload-time re-layout (reference layout -> device layout, see above)
+// ---------------------------------------------------------------------------
+__global__ void relayout_nodes_kernel(const int32_t* child, const uint16_t* data, uint32_t* nodes,
+                                      int64_t n_slots, int N3, int data_dim) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    const int32_t skip = child[i];
+    uint32_t w;
+    if (skip == 0) {
+        w = kLeafBit | (uint32_t)data[i * data_dim + (data_dim - 1)];
+    } else {
+        w = (uint32_t)((i / N3) + skip);
+    }
+    nodes[i] = w;
+}
+
+// one thread per 16-byte chunk of the padded record array
+__global__ void relayout_leaves_kernel(const uint16_t* data, uint16_t* leaves, int64_t n_slots,
+                                       int data_dim, int stride_h) {
+    const int chunks = stride_h / 8;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t slot = gid / chunks;
+    if (slot >= n_slots) return;
+    const int c = (int)(gid - slot * chunks);
+    const uint16_t* src = data + slot * data_dim;
+    uint16_t h[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int e = c * 8 + j;
+        h[j] = e < data_dim - 1 ? src[e] : (uint16_t)0;
+    }
+    uint4 q;
+    q.x = h[0] | ((uint32_t)h[1] << 16);
+    q.y = h[2] | ((uint32_t)h[3] << 16);
+    q.z = h[4] | ((uint32_t)h[5] << 16);
+    q.w = h[6] | ((uint32_t)h[7] << 16);
+    reinterpret_cast<uint4*>(leaves + slot * stride_h)[c] = q;
+}
+
+// grid[cell] = deepest node at level <= G that contains the cell
+__global__ void build_grid_kernel(const uint32_t* nodes, uint32_t* grid, int G) {
+    const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_cells = 1u << (3 * G);
+    if (cell >= n_cells) return;
+    const uint32_t mask = (1u << G) - 1u;
+    const uint32_t cx = (cell >> (2 * G)) & mask, cy = (cell >> G) & mask, cz = cell & mask;
+    uint32_t node = 0;
+    int l = 0;
+    for (; l < G; ++l) {
+        const int sh = G - 1 - l;
+        const uint32_t slot = (((cx >> sh) & 1u) << 2) | (((cy >> sh) & 1u) << 1) | ((cz >> sh) & 1u);
+        const uint32_t w = nodes[(uint64_t)node * 8u + slot];
+        if (w & kLeafBit) break;
+        node = w;
+    }
+    grid[cell] = ((uint32_t)l << kGridNodeBits) | node;
 }
 
 template <int FMA, int MODE>
@@ -626,6 +835,33 @@ hipError_t launch_probe(const KParams& p, const float probe[3], float* out_dev,
                         hipStream_t stream) {
     hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, stream, p, probe[0], probe[1],
                        probe[2], out_dev);
+    return hipGetLastError();
+}
+
+int leaf_stride_halfs(int data_dim) {
+    const int bytes = 2 * (data_dim - 1);
+    int stride = 16;
+    while (stride < bytes && stride < 128) stride *= 2;  // 16, 32, 64, 128: never straddles a line
+    if (stride < bytes) stride = (bytes + 31) / 32 * 32;
+    return stride / 2;
+}
+
+hipError_t launch_relayout(const int32_t* child, const uint16_t* data, uint32_t* nodes,
+                           uint16_t* leaves, int64_t n_slots, int N3, int data_dim, int stride_h,
+                           hipStream_t stream) {
+    const int tpb = 256;
+    hipLaunchKernelGGL(relayout_nodes_kernel, dim3((unsigned)((n_slots + tpb - 1) / tpb)), dim3(tpb),
+                       0, stream, child, data, nodes, n_slots, N3, data_dim);
+    const int64_t n_chunks = n_slots * (stride_h / 8);
+    hipLaunchKernelGGL(relayout_leaves_kernel, dim3((unsigned)((n_chunks + tpb - 1) / tpb)),
+                       dim3(tpb), 0, stream, data, leaves, n_slots, data_dim, stride_h);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_grid(const uint32_t* nodes, uint32_t* grid, int G, hipStream_t stream) {
+    const uint32_t n_cells = 1u << (3 * G);
+    hipLaunchKernelGGL(build_grid_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, stream, nodes,
+                       grid, G);
     return hipGetLastError();
 }
 
