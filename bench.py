@@ -66,40 +66,52 @@ def load_or_make_tree(synth, name: str, local_rank: int, barrier):
                            dict(config=name))
 
 
-def cpu_baseline(tree, transform, width, height, focal, budget_s=12.0):
-    """Oracle (strict) on all host cores over a bounded sample: centre rows of the
-    frame, 8 rows at a time, until ~budget_s of CPU time has been spent."""
+def cpu_baseline(tree, transforms, width, height, focal, budget_s=12.0):
+    """Oracle (strict mode) on all host cores over a bounded sample of the same workload:
+    whole frames of the pose orbit, one after the other, until ~budget_s of wall time is
+    spent (at least one frame; a 64-row centre band first if a frame would not fit)."""
     from oracle import binding as ob
     th = ob.TreeHandle(tree)
-    cam = ob.make_camera(transform, width, height, focal)
     opt = ob.default_options()
     cores = os.cpu_count() or 1
-    rays = 0
-    t_total = 0.0
-    y = (height // 2) // 8 * 8
-    bands = 0
-    while t_total < budget_s and y + 8 <= height:
+    cam = ob.make_camera(transforms[0], width, height, focal)
+    y0 = max(0, (height // 2 - 32) // 8 * 8)
+    rows = min(64, height - y0)
+    t0 = time.perf_counter()
+    ob.render(th, cam, opt, ob.FP_STRICT, region=(0, y0, width, rows), want_accum=False,
+              nthreads=cores)
+    t_band = time.perf_counter() - t0
+    est_frame = t_band * height / rows
+    if est_frame > 2.5 * budget_s:  # slow host: the band is the sample
+        mrays = width * rows / t_band / 1e6
+        return {"value": round(mrays, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                "sample": f"{rows}-row centre band of pose 0 ({width * rows} rays), "
+                          f"{t_band:.1f}s, oracle strict mode, {cores} threads"}
+    rays, t_total, n = 0, 0.0, 0
+    while t_total < budget_s and n < len(transforms):
+        cam = ob.make_camera(transforms[n], width, height, focal)
         t0 = time.perf_counter()
-        ob.render(th, cam, opt, ob.FP_STRICT, region=(0, y, width, 8), want_accum=False,
-                  nthreads=cores)
+        ob.render(th, cam, opt, ob.FP_STRICT, want_accum=False, nthreads=cores)
         t_total += time.perf_counter() - t0
-        rays += width * 8
-        y += 8
-        bands += 1
+        rays += width * height
+        n += 1
     mrays = rays / t_total / 1e6
     return {"value": round(mrays, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{bands} 8-row bands ({rays} rays) from the image centre of pose 0, "
+            "sample": f"{n} full {width}x{height} frames (poses 0..{n - 1}, {rays} rays), "
                       f"{t_total:.1f}s, oracle strict mode, {cores} threads"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=208)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--config", default="C1", choices=["C0", "C1", "C2", "C3"])
     ap.add_argument("--fp", default="strict", choices=["strict", "fma"])
     ap.add_argument("--tile-rows", type=int, default=8, help="rows per interleaved screen tile")
+    ap.add_argument("--batch", type=int, default=16,
+                    help="poses per launch (vr_render_batch); steps must be a multiple")
+    ap.add_argument("--tune", default="", help="k=v,... scheduling knobs (march_max, refill_min, waves_per_cu)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -140,80 +152,110 @@ def main():
     opts = api.RenderOptions()
     fp_mode = _abi.FP_FMA if args.fp == "fma" else _abi.FP_STRICT
     stream = torch.cuda.current_stream()
+    if args.tune:
+        api.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
 
+    B = max(1, min(args.batch, 16))
     tile_h = max(8, (args.tile_rows // 8) * 8)
     tile_w = (W + 7) // 8 * 8
     shard = api.TileShard(tile_w, tile_h, rank, world, compact=True)
-    frame = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+    # double-buffered outputs: launch j writes set j % 2
+    frames = [[torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
+              for _ in range(2)]
     if world > 1:
         nbytes = api.compact_bytes(W, H, shard)
-        bufs = [torch.zeros(nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
-        gathered = [torch.zeros((world, nbytes), dtype=torch.uint8, device=dev)
+        bufs = [torch.zeros((B, nbytes), dtype=torch.uint8, device=dev) for _ in range(2)]
+        gathered = [torch.zeros((world, B, nbytes), dtype=torch.uint8, device=dev)
                     for _ in range(2)] if rank == 0 else [None, None]
 
-    def render_step(i, ev=None):
-        cam.transform = transforms[i % len(transforms)]
+    def pose_of(step):
+        return transforms[step % len(transforms)]
+
+    def render_launch(j, first_step, n, ev=None):
+        """Launch j renders steps [first_step, first_step+n) in one batch."""
+        tr = [pose_of(first_step + i) for i in range(n)]
         if ev is not None:
             ev[0].record(stream)
         if world == 1:
-            api.launch_renderer(tree, cam, opts, frame, None, stream, True, fp_mode=fp_mode)
+            api.launch_renderer_batch(tree, cam, tr, opts, frames[j % 2][:n], stream, True,
+                                      fp_mode=fp_mode)
         else:
-            api.launch_renderer(tree, cam, opts, bufs[i % 2], None, stream, True, shard=shard,
-                                fp_mode=fp_mode)
+            api.launch_renderer_batch(tree, cam, tr, opts, [bufs[j % 2][i] for i in range(n)],
+                                      stream, True, shard=shard, fp_mode=fp_mode)
         if ev is not None:
             ev[1].record(stream)
 
     works = {}
 
-    def gather_step(i):
+    def gather_launch(j):
         if world == 1:
             return
         if rank == 0:
-            glist = [gathered[i % 2][r] for r in range(world)]
-            works[i] = dist.gather(bufs[i % 2], glist, dst=0, async_op=True)
+            glist = [gathered[j % 2][r] for r in range(world)]
+            works[j] = dist.gather(bufs[j % 2], glist, dst=0, async_op=True)
         else:
-            works[i] = dist.gather(bufs[i % 2], None, dst=0, async_op=True)
+            works[j] = dist.gather(bufs[j % 2], None, dst=0, async_op=True)
 
-    def retire(i):
-        """Frame i's gather must be complete before its buffers are reused."""
-        if world == 1 or i not in works:
+    def retire(j, n):
+        """Launch j's gather must be complete before its buffers are reused."""
+        if world == 1 or j not in works:
             return
-        works.pop(i).wait()
+        works.pop(j).wait()
         if rank == 0:
-            api.assemble_tiles(frame, gathered[i % 2], W, H, shard, stream)
+            for i in range(n):
+                # rank-major stack of this frame's compact buffers
+                api.assemble_tiles(frames[j % 2][i], gathered[j % 2][:, i].contiguous(), W, H,
+                                   shard, stream)
 
     def run(n_steps, first, events=None):
-        for s in range(n_steps):
-            i = first + s
-            retire(i - 2)
-            render_step(i, events[s] if events else None)
-            gather_step(i)
-        retire(first + n_steps - 2)
-        retire(first + n_steps - 1)
+        sizes = []
+        j = 0
+        done = 0
+        while done < n_steps:
+            n = min(B, n_steps - done)
+            if j >= 2:
+                retire(j - 2, sizes[j - 2])
+            render_launch(j, first + done, n, events[j] if events else None)
+            gather_launch(j)
+            sizes.append(n)
+            done += n
+            j += 1
+        for jj in (j - 2, j - 1):
+            if jj >= 0:
+                retire(jj, sizes[jj])
+        return j
 
     # ---- warm-up (untimed) ---------------------------------------------------
     run(args.warmup, 0)
     torch.cuda.synchronize()
 
-    # ---- algorithmic bytes per launch: instrumented flavour, outside the timed region
+    # ---- algorithmic bytes: instrumented flavour, outside the timed region -----
     K = args.steps
     n_distinct = min(K, len(transforms))
-    counters = torch.zeros(7, dtype=torch.int64, device=dev)
-    scratch = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+    counters = torch.zeros((B, 7), dtype=torch.int64, device=dev)
+    scratch = [torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
     full = api.TileShard(tile_w, tile_h, rank, world, compact=False)
-    for j in range(n_distinct):
-        cam.transform = transforms[(args.warmup + j) % len(transforms)]
-        api.launch_renderer(tree, cam, opts, scratch, None, stream, True, shard=full,
-                            fp_mode=fp_mode, counters=counters)
+    jd = 0
+    while jd < n_distinct:  # same batching as the timed region
+        n = min(B, n_distinct - jd)
+        tr = [pose_of(args.warmup + jd + i) for i in range(n)]
+        api.launch_renderer_batch(tree, cam, tr, opts, scratch[:n], stream, True, shard=full,
+                                  fp_mode=fp_mode, counters=[counters[i] for i in range(n)])
+        jd += n
     torch.cuda.synchronize()
-    cnt = dict(zip(_abi.COUNTER_FIELDS, [int(v) for v in counters.cpu().tolist()]))
-    reps = K / n_distinct
-    alg_bytes_per_launch = cnt["alg_bytes"] / n_distinct  # this rank's launches
+    cnt = dict(zip(_abi.COUNTER_FIELDS, [int(v) for v in counters.sum(dim=0).cpu().tolist()]))
+    alg_bytes_per_frame = cnt["alg_bytes"] / n_distinct  # this rank's share of a frame
+    sched = tree.sched_stats()
+    log(f"[bench r{rank}] sched per frame: " + ", ".join(
+        f"{k}={v / n_distinct:.0f}" for k, v in sched.items()) +
+        f"; march util {sched['march_lanes'] / max(64 * sched['march_rounds'], 1):.2f}"
+        f", shade util {sched['shade_lanes'] / max(64 * sched['shade_rounds'], 1):.2f}")
     del scratch
 
     # ---- timed region ----------------------------------------------------------
+    n_launch = (K + B - 1) // B
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(K)]
+              for _ in range(n_launch)]
     barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
@@ -228,9 +270,10 @@ def main():
         elapsed = float(tmax.item())
 
     kern_ms = [a.elapsed_time(b) for a, b in events]
-    kern_mean_s = float(np.mean(kern_ms)) / 1e3
+    kern_total_s = float(np.sum(kern_ms)) / 1e3
+    kern_mean_s = kern_total_s / n_launch
+    alg_bytes_per_launch = alg_bytes_per_frame * K / n_launch
 
-    result = None
     if rank == 0:
         rays_total = W * H * K
         mrays = rays_total / elapsed / 1e6
@@ -255,9 +298,10 @@ def main():
                             f"{info['device_bytes'] / 1e9:.2f} GB in HBM, {W}x{H}, "
                             f"fx=fy={focal}, 200-pose orbit, default RenderOptions",
                 "fp_mode": args.fp,
+                "frames_per_launch": B,
                 "parallelism": "single GPU" if world == 1 else
                                f"screen tiles {tile_w}x{tile_h} round-robin over {world} GPUs, "
-                               f"tree replicated, RCCL gather of RGBA8 to rank 0 per frame",
+                               f"tree replicated, one RCCL gather of RGBA8 to rank 0 per launch",
             },
             "roofline": {
                 "bound": "hbm",
@@ -266,8 +310,9 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": None,
-                "kernel": "vr::render_kernel<strict|fma, SH16, FAST>",
+                "kernel": "vr::render_kernel<fp, SH16, FAST> (persistent, %d frames per launch)" % B,
                 "kernel_ms_mean": round(kern_mean_s * 1e3, 5),
+                "kernel_ms_per_frame": round(kern_total_s / K * 1e3, 5),
                 "alg_bytes_per_launch": int(alg_bytes_per_launch),
                 "samples_per_ray": round(cnt["samples"] / max(cnt["rays"], 1), 2),
                 "hit_samples_per_ray": round(cnt["hit_samples"] / max(cnt["rays"], 1), 2),
@@ -275,8 +320,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(stree, transforms[0], W, H, focal,
-                                                  args.cpu_budget)
+            result["cpu_baseline"] = cpu_baseline(stree, transforms, W, H, focal, args.cpu_budget)
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)

@@ -179,6 +179,21 @@ void vr_default_frame(VrFrame* frame);
 int64_t vr_compact_bytes(int width, int height, int tile_w, int tile_h, int world);
 int vr_render(vr_tree_t tree, const VrCamera* cam, const VrRenderOptions* opt,
               const VrFrame* frame, void* stream);
+/* Several poses in ONE launch (the volrend_headless pose loop, main_headless.cpp:207-225,
+ * known up front): cams[i] -> frames[i].  All entries must share image size,
+ * intrinsics, layout, sharding and fp_mode; only the pose and the buffers differ.
+ * A single 800x800 frame cannot fill 256 CUs; a batch can.  1 <= n <= VR_MAX_BATCH. */
+#define VR_MAX_BATCH 16
+int vr_render_batch(vr_tree_t tree, int n_frames, const VrCamera* cams,
+                    const VrRenderOptions* opt, const VrFrame* frames, void* stream);
+/* Scheduling knobs of the persistent kernel ("march_max", "refill_min",
+ * "waves_per_cu"); results never depend on them. */
+int vr_set_tuning(const char* key, int value);
+/* Scheduling tallies accumulated by instrumented launches (frames with counters):
+ * [0] march rounds [1] lanes busy in them [2] shade rounds [3] lanes busy in them
+ * [4] cache fills [5] retire rounds [6] rays retired in them [7] scheduler iterations.
+ * Synchronous (copies from the device); reset != 0 clears them. */
+int vr_sched_stats(vr_tree_t tree, uint64_t out[8], int reset);
 /* gathered = world consecutive COMPACT buffers (rank-major), all device memory
  * on the current device.  Writes the W x H frame. */
 int vr_assemble_tiles(void* frame_rgba, int64_t pitch, const void* gathered, int width,

@@ -47,7 +47,7 @@ typedef struct Job {
     const uint8_t* rgba_init;
     const float* depth_init;
     const float* probe_coeffs;
-    int next_row; /* atomic row dispenser */
+    long next_item; /* atomic work dispenser */
     pthread_mutex_t mu;
     OrCounters total;
 } Job;
@@ -66,11 +66,16 @@ static void* worker(void* arg) {
     Job* j = (Job*)arg;
     OrCounters local;
     memset(&local, 0, sizeof(local));
+    const int chunk = 32; /* pixels per work item */
+    const int per_row = (j->w + chunk - 1) / chunk;
+    const long n_items = (long)per_row * j->h;
     for (;;) {
-        const int row = __atomic_fetch_add(&j->next_row, 1, __ATOMIC_RELAXED);
-        if (row >= j->h) break;
-        const int y = j->y0 + row;
-        for (int x = j->x0; x < j->x0 + j->w; ++x) {
+        const long item = __atomic_fetch_add(&j->next_item, 1, __ATOMIC_RELAXED);
+        if (item >= n_items) break;
+        const int y = j->y0 + (int)(item / per_row);
+        const int xs = j->x0 + (int)(item % per_row) * chunk;
+        const int xe = xs + chunk < j->x0 + j->w ? xs + chunk : j->x0 + j->w;
+        for (int x = xs; x < xe; ++x) {
             if (j->fp_mode == OR_FP_FMA)
                 render_pixel_fma(j->tree, j->cam, j->opt, j->offscreen, x, y, j->rgba, j->accum,
                                  j->rgba_init, j->depth_init, j->probe_coeffs, &local);

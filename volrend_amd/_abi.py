@@ -76,6 +76,10 @@ PROTOTYPES = {
     "vr_compact_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vr_render": (C.c_int, [C.c_void_p, C.POINTER(VrCamera), C.POINTER(VrRenderOptions),
                             C.POINTER(VrFrame), C.c_void_p]),
+    "vr_render_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(VrCamera),
+                                  C.POINTER(VrRenderOptions), C.POINTER(VrFrame), C.c_void_p]),
+    "vr_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "vr_sched_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 8), C.c_int]),
     "vr_assemble_tiles": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_void_p]),
     "vr_probe_coeffs": (C.c_int, [C.c_void_p, C.POINTER(VrRenderOptions), C.c_void_p, C.c_void_p]),

@@ -243,6 +243,14 @@ class N3Tree:
         """n3tree.cpp:441-447: keeps ``child_`` (wireframes), drops ``data_``."""
         self.data_ = None
 
+    def sched_stats(self, reset: bool = True) -> dict:
+        """Scheduling tallies of instrumented launches (see vr_sched_stats)."""
+        out = (C.c_uint64 * 8)()
+        _abi.check(_abi.lib().vr_sched_stats(self._handle, C.byref(out), 1 if reset else 0))
+        names = ("march_rounds", "march_lanes", "shade_rounds", "shade_lanes", "fills",
+                 "retire_rounds", "retired", "iterations")
+        return dict(zip(names, [int(v) for v in out]))
+
     def info(self) -> dict:
         i = _abi.VrTreeInfo()
         _abi.check(_abi.lib().vr_tree_info(self._handle, C.byref(i)))
@@ -349,6 +357,47 @@ def launch_renderer(tree: N3Tree, cam: Camera, options: RenderOptions, image, de
     c = cam.to_c()
     o = options.to_c()
     _abi.check(L.vr_render(tree.handle, C.byref(c), C.byref(o), C.byref(f), _stream_ptr(stream)))
+
+
+def launch_renderer_batch(tree: N3Tree, cam: Camera, transforms, options: RenderOptions, images,
+                          stream=None, offscreen: bool = True, *, accums=None, depths=None,
+                          pitch: int = 0, shard: TileShard | None = None,
+                          fp_mode: int = _abi.FP_STRICT, counters=None) -> None:
+    """Several poses in ONE launch: ``transforms[i]`` (12-float c2w) -> ``images[i]``.
+
+    The pose loop of ``volrend_headless`` (main_headless.cpp:207-225) with the
+    poses known up front; intrinsics / options / sharding are shared.  ``counters``:
+    optional list of device int64[7] tensors (instrumented flavour)."""
+    n = len(transforms)
+    if n != len(images):
+        raise ValueError("one image per pose")
+    L = _abi.lib()
+    cams = (_abi.VrCamera * n)()
+    frames = (_abi.VrFrame * n)()
+    for i in range(n):
+        cam.transform = np.asarray(transforms[i], dtype=np.float32)
+        cams[i] = cam.to_c()
+        f = frames[i]
+        L.vr_default_frame(C.byref(f))
+        f.rgba = _ptr(images[i])
+        f.pitch = pitch
+        f.depth = _ptr(depths[i]) if depths else None
+        f.accum = _ptr(accums[i]) if accums else None
+        f.offscreen = 1 if offscreen else 0
+        f.fp_mode = fp_mode
+        f.counters = _ptr(counters[i]) if counters else None
+        if shard is not None:
+            f.tile_w, f.tile_h, f.rank, f.world = (shard.tile_w, shard.tile_h, shard.rank,
+                                                   shard.world)
+            f.layout = _abi.LAYOUT_COMPACT if shard.compact else _abi.LAYOUT_FRAME
+    o = options.to_c()
+    _abi.check(L.vr_render_batch(tree.handle, n, cams, C.byref(o), frames, _stream_ptr(stream)))
+
+
+def set_tuning(**kw) -> None:
+    """Scheduling knobs of the persistent kernel (march_max, refill_min, waves_per_cu)."""
+    for k, v in kw.items():
+        _abi.check(_abi.lib().vr_set_tuning(k.encode(), int(v)))
 
 
 def compact_bytes(width: int, height: int, shard: TileShard) -> int:

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -26,6 +27,26 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// Scheduling knobs of the persistent kernel (env VR_MARCH_MAX / VR_REFILL_MIN /
+// VR_WAVES_PER_CU at first use, or vr_set_tuning).  They never change results.
+struct Tuning {
+    int march_max = 2;
+    int refill_min = 16;
+    int waves_per_cu = 20;
+    int shade_min = 48;
+};
+Tuning& tuning() {
+    static Tuning tn = [] {
+        Tuning x;
+        if (const char* e = getenv("VR_MARCH_MAX")) x.march_max = atoi(e) < 1 ? 1 : atoi(e);
+        if (const char* e = getenv("VR_REFILL_MIN")) x.refill_min = atoi(e) < 1 ? 1 : atoi(e);
+        if (const char* e = getenv("VR_WAVES_PER_CU")) x.waves_per_cu = atoi(e) < 1 ? 1 : atoi(e);
+        if (const char* e = getenv("VR_SHADE_MIN")) x.shade_min = atoi(e) < 1 ? 1 : atoi(e);
+        return x;
+    }();
+    return tn;
+}
+
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \
@@ -37,6 +58,8 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace
 
+constexpr unsigned kLaunchSlots = 4;
+
 struct VrTreeOpaque {
     int device = 0;
     uint32_t* nodes = nullptr;   // device layout (vr_kernels.hip)
@@ -46,7 +69,16 @@ struct VrTreeOpaque {
     int leaf_stride_h = 0;
     float* extra = nullptr;
     uint32_t* status = nullptr;
+    unsigned long long* sched_stats = nullptr;  // 8 x u64, see vr_sched_stats
     float* probe_buf = nullptr;  // data_dim floats: the lumisphere at opt.probe
+    // Launch slots: every launch takes the next slot of a ring for its per-frame table
+    // and ray-queue head, so up to kLaunchSlots launches may be in flight (any streams).
+    vr::FrameDesc* slot_frames = nullptr;
+    uint32_t* slot_heads = nullptr;      // per slot: [0] queue head, [1] ray count
+    uint32_t* slot_rays[kLaunchSlots] = {};   // per slot: ray buffer, grown on demand
+    size_t slot_ray_bytes[kLaunchSlots] = {};
+    std::atomic<unsigned> launch_seq{0};
+    int n_cus = 256;
     VrTreeDesc desc{};  // pointers cleared; scalars kept
     int32_t max_depth = 0;
     uint64_t device_bytes = 0;
@@ -132,6 +164,7 @@ void fill_tree_params(vr::KParams& k, const VrTreeOpaque* t) {
     k.ndc_height = t->desc.ndc_height;
     k.ndc_focal = t->desc.ndc_focal;
     k.status = t->status;
+    k.sched_stats = t->sched_stats;
 }
 
 }  // namespace
@@ -243,7 +276,18 @@ int vr_tree_upload(const VrTreeDesc* d, vr_tree_t* out) {
     if (e == hipSuccess) e = hipMalloc((void**)&t->leaves, leaves_sz);
     if (e == hipSuccess) e = hipMalloc((void**)&t->status, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(t->status, 0, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&t->sched_stats, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(t->sched_stats, 0, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&t->probe_buf, sizeof(float) * (size_t)d->data_dim);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&t->slot_frames, sizeof(vr::FrameDesc) * vr::kMaxBatch * kLaunchSlots);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->slot_heads, sizeof(uint32_t) * 2 * kLaunchSlots);
+    if (e == hipSuccess) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) ==
+                hipSuccess && cus > 0)
+            t->n_cus = cus;
+    }
     if (e == hipSuccess)
         e = vr::launch_relayout(src_child, src_data, t->nodes, t->leaves, (int64_t)n_slots, N3,
                                 d->data_dim, t->leaf_stride_h, nullptr);
@@ -292,7 +336,12 @@ int vr_tree_free(vr_tree_t t) {
     if (t->grid) (void)hipFree(t->grid);
     if (t->extra) (void)hipFree(t->extra);
     if (t->status) (void)hipFree(t->status);
+    if (t->sched_stats) (void)hipFree(t->sched_stats);
     if (t->probe_buf) (void)hipFree(t->probe_buf);
+    if (t->slot_frames) (void)hipFree(t->slot_frames);
+    if (t->slot_heads) (void)hipFree(t->slot_heads);
+    for (unsigned i = 0; i < kLaunchSlots; ++i)
+        if (t->slot_rays[i]) (void)hipFree(t->slot_rays[i]);
     delete t;
     return VR_OK;
 }
@@ -361,10 +410,31 @@ int64_t vr_compact_bytes(int width, int height, int tile_w, int tile_h, int worl
     return per_rank * tw * th * 4;
 }
 
-int vr_render(vr_tree_t t, const VrCamera* cam, const VrRenderOptions* opt, const VrFrame* f,
-              void* stream) {
-    if (!t || !cam || !opt || !f) return fail(VR_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (!f->rgba) return fail(VR_ERR_INVALID_ARGUMENT, "frame->rgba is NULL");
+int vr_set_tuning(const char* key, int value) {
+    if (!key) return fail(VR_ERR_INVALID_ARGUMENT, "key is NULL");
+    Tuning& tn = tuning();
+    if (!strcmp(key, "march_max")) tn.march_max = value < 1 ? 1 : value;
+    else if (!strcmp(key, "refill_min")) tn.refill_min = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (!strcmp(key, "waves_per_cu")) tn.waves_per_cu = value < 1 ? 1 : (value > 32 ? 32 : value);
+    else if (!strcmp(key, "shade_min")) tn.shade_min = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else return fail(VR_ERR_INVALID_ARGUMENT, "unknown tuning key '%s'", key);
+    return VR_OK;
+}
+
+int vr_sched_stats(vr_tree_t t, uint64_t out[8], int reset) {
+    if (!t || !out) return fail(VR_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipMemcpy(out, t->sched_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(t->sched_stats, 0, 8 * sizeof(uint64_t)));
+    return VR_OK;
+}
+
+int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRenderOptions* opt,
+                    const VrFrame* frames, void* stream) {
+    if (!t || !cams || !opt || !frames) return fail(VR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_frames < 1 || n_frames > VR_MAX_BATCH)
+        return fail(VR_ERR_INVALID_ARGUMENT, "n_frames=%d outside [1,%d]", n_frames, VR_MAX_BATCH);
+    const VrFrame* f = &frames[0];
+    const VrCamera* cam = &cams[0];
     if (f->fp_mode != VR_FP_STRICT && f->fp_mode != VR_FP_FMA)
         return fail(VR_ERR_INVALID_ARGUMENT, "unknown fp_mode %d", f->fp_mode);
     if (f->layout != VR_LAYOUT_FRAME && f->layout != VR_LAYOUT_COMPACT)
@@ -373,10 +443,33 @@ int vr_render(vr_tree_t t, const VrCamera* cam, const VrRenderOptions* opt, cons
     if (f->rank < 0 || f->rank >= world)
         return fail(VR_ERR_INVALID_ARGUMENT, "rank %d outside world %d", f->rank, world);
 
+    vr::FrameTable tbl;
+    memset(&tbl, 0, sizeof(tbl));
+    tbl.n = n_frames;
+    bool instrumented = false;
+    for (int i = 0; i < n_frames; ++i) {
+        const VrFrame& fi = frames[i];
+        const VrCamera& ci = cams[i];
+        if (!fi.rgba) return fail(VR_ERR_INVALID_ARGUMENT, "frame %d: rgba is NULL", i);
+        // one launch shares everything but the pose and the buffers
+        if (ci.width != cam->width || ci.height != cam->height || ci.fx != cam->fx ||
+            ci.fy != cam->fy)
+            return fail(VR_ERR_INVALID_ARGUMENT, "frame %d: intrinsics differ within the batch", i);
+        if (fi.pitch != f->pitch || fi.offscreen != f->offscreen || fi.layout != f->layout ||
+            fi.tile_w != f->tile_w || fi.tile_h != f->tile_h || fi.rank != f->rank ||
+            fi.world != f->world || fi.fp_mode != f->fp_mode)
+            return fail(VR_ERR_INVALID_ARGUMENT, "frame %d: layout/shard/fp_mode differ within the batch", i);
+        memcpy(tbl.f[i].xf, ci.transform, sizeof(tbl.f[i].xf));
+        tbl.f[i].rgba = static_cast<uint8_t*>(fi.rgba);
+        tbl.f[i].accum = fi.accum;
+        tbl.f[i].depth = fi.depth;
+        tbl.f[i].counters = reinterpret_cast<unsigned long long*>(fi.counters);
+        instrumented = instrumented || fi.counters != nullptr;
+    }
+
     vr::KParams k;
     memset(&k, 0, sizeof(k));
     fill_tree_params(k, t);
-    memcpy(k.xf, cam->transform, sizeof(k.xf));
     k.width = cam->width;
     k.height = cam->height;
     k.fx = cam->fx;
@@ -417,23 +510,53 @@ int vr_render(vr_tree_t t, const VrCamera* cam, const VrRenderOptions* opt, cons
     k.wblocks_per_tile_x = k.tile_w / 8;
     k.wblocks_per_tile = (k.tile_w / 8) * (k.tile_h / 8);
     k.n_wave_blocks = (int64_t)k.n_local_tiles * k.wblocks_per_tile;
-    k.rgba = static_cast<uint8_t*>(f->rgba);
+    const int64_t total = k.n_wave_blocks * 64 * n_frames;
+    if (total >= (1ll << 32))
+        return fail(VR_ERR_INVALID_ARGUMENT, "batch of %lld rays exceeds the 32-bit ray queue",
+                    (long long)total);
+    k.total_rays = (uint32_t)total;
+    k.n_frames = n_frames;
     k.pitch = f->pitch ? f->pitch : (int64_t)cam->width * 4;
-    k.depth = f->depth;
-    k.accum = f->accum;
     k.offscreen = f->offscreen != 0;
     k.layout = f->layout;
-    k.counters = reinterpret_cast<unsigned long long*>(f->counters);
-    {
-        const char* env = getenv("VR_XCD_REMAP");
-        k.xcd_remap = env ? atoi(env) : 0;
-        const char* mm = getenv("VR_MARCH_MAX");
-        k.march_max = mm ? atoi(mm) : 2;
-        if (k.march_max < 1) k.march_max = 1;
+    k.instrumented = instrumented ? 1 : 0;
+    const Tuning& tn = tuning();
+    k.march_max = tn.march_max;
+    k.refill_min = tn.refill_min;
+    k.shade_min = tn.shade_min;
+    // launch slot: frame table + queue head in device memory (ring, see VrTreeOpaque)
+    const unsigned slot = t->launch_seq.fetch_add(1) % kLaunchSlots;
+    k.frames = t->slot_frames + (size_t)slot * vr::kMaxBatch;
+    k.queue_head = t->slot_heads + 2 * slot;
+    k.ray_count_rw = t->slot_heads + 2 * slot + 1;
+    k.ray_count = k.ray_count_rw;
+    // basis words kept per ray: what the kernel flavour for this basis_dim reads
+    const int bd = t->desc.basis_dim;
+    k.basis_words = (t->desc.format == VR_FORMAT_RGBA || bd < 0)
+                        ? 0
+                        : ((bd == 4 || bd == 9 || bd == 16 || bd == 25) ? bd : 1);
+    const size_t need = (size_t)k.total_rays * (15 + (size_t)k.basis_words) * sizeof(uint32_t);
+    if (t->slot_ray_bytes[slot] < need) {  // first use of the slot / larger batch: (re)allocate
+        if (t->slot_rays[slot]) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(t->slot_rays[slot]));
+            t->slot_rays[slot] = nullptr;
+            t->slot_ray_bytes[slot] = 0;
+        }
+        HIP_TRY(hipMalloc((void**)&t->slot_rays[slot], need));
+        t->slot_ray_bytes[slot] = need;
     }
+    k.ray_buf_rw = t->slot_rays[slot];
+    k.ray_buf = k.ray_buf_rw;
 
-    HIP_TRY(vr::launch_render(k, f->fp_mode, static_cast<hipStream_t>(stream)));
+    HIP_TRY(vr::launch_render(k, tbl, f->fp_mode, t->n_cus * tn.waves_per_cu,
+                              static_cast<hipStream_t>(stream)));
     return VR_OK;
+}
+
+int vr_render(vr_tree_t t, const VrCamera* cam, const VrRenderOptions* opt, const VrFrame* f,
+              void* stream) {
+    return vr_render_batch(t, 1, cam, opt, f, stream);
 }
 
 int vr_assemble_tiles(void* frame_rgba, int64_t pitch, const void* gathered, int width, int height,

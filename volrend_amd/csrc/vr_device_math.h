@@ -61,9 +61,10 @@ static __device__ __forceinline__ float h2f(uint16_t h) {
 //   clamp to [-104, 89]; k = rint(x*log2e); r = x - k*ln2 (two-step Cody-Waite);
 //   degree-5 Horner (Cephes coefficients); result = (y*2^(k>>1)) * 2^(k-(k>>1)).
 static __device__ __forceinline__ float vr_expf(float x) {
-    if (x != x) return x;
-    x = x < -104.0f ? -104.0f : x;
-    x = x > 89.0f ? 89.0f : x;
+    // Branch-free form of the spec: v_med3_f32 is the clamp (a NaN stays a NaN
+    // through the fma chain), v_ldexp_f32 is the single-rounding power-of-two
+    // scaling (identical to the spec's two exact-then-rounded multiplies).
+    x = __builtin_amdgcn_fmed3f(x, -104.0f, 89.0f);
     const float kf = __builtin_rintf(x * 1.44269502162933349609375f);
     float r = __builtin_fmaf(kf, -0.693145751953125f, x);
     r = __builtin_fmaf(kf, -1.428606765330187045037746429443359375e-06f, r);
@@ -76,12 +77,7 @@ static __device__ __forceinline__ float vr_expf(float x) {
     const float r2 = r * r;
     float y = __builtin_fmaf(p, r2, r);
     y = y + 1.0f;
-    const int k = (int)kf;
-    const int k1 = k >> 1;
-    const int k2 = k - k1;
-    const float s1 = u2f((uint32_t)(k1 + 127) << 23);
-    const float s2 = u2f((uint32_t)(k2 + 127) << 23);
-    return (y * s1) * s2;
+    return __builtin_amdgcn_ldexpf(y, (int)kf);
 }
 
 template <int FMA>

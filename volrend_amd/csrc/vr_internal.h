@@ -8,15 +8,32 @@
 
 namespace vr {
 
-// Everything the render kernel needs, passed BY VALUE as the kernel argument
+constexpr int kMaxBatch = 16;  // frames per launch (VR_MAX_BATCH)
+
+// Per-frame part of a launch: pose and buffers.  Lives in device memory (one
+// small table per launch slot) because lanes of one wave may hold rays of
+// different frames.
+struct FrameDesc {
+    float xf[12];  // column-major 4x3 c2w (CameraSpec.transform)
+    uint8_t* rgba;
+    float* accum;
+    const float* depth;
+    unsigned long long* counters;  // optional VrCounters (7 x u64)
+};
+
+struct FrameTable {
+    int32_t n;
+    FrameDesc f[kMaxBatch];
+};
+
+// Everything else the render kernel needs, passed BY VALUE as the kernel argument
 // (the reference passes CameraSpec + TreeSpec + RenderOptions by value and the
-// 12-float pose through a 48-byte H2D copy per frame, src/camera.cpp:67-75;
-// here the pose rides in the argument block, so a frame is exactly one launch).
+// 12-float pose through a 48-byte H2D copy per frame, src/camera.cpp:67-75).
 struct KParams {
-    // ---- tree (TreeSpec, data_spec.hpp:23-50) ----
-    const uint32_t* nodes;    // device layout: one word per child slot (vr_kernels.hip)
-    const uint16_t* leaves;   // device layout: padded coefficient records
-    const uint32_t* grid;     // device layout: top-level restart grid (N == 2) or NULL
+    // ---- tree (TreeSpec, data_spec.hpp:23-50), device layout ----
+    const uint32_t* nodes;    // one word per child slot (vr_kernels.hip)
+    const uint16_t* leaves;   // padded coefficient records
+    const uint32_t* grid;     // top-level restart grid (N == 2) or NULL
     const float* extra;
     float offset[3];
     float scale[3];
@@ -27,11 +44,8 @@ struct KParams {
     int32_t leaf_stride_h;    // fp16 elements between padded records
     int32_t max_depth;        // deepest leaf level (child words read - 1)
     int32_t grid_levels;      // G: grid has 2^G cells per axis (0 = no grid)
-    int32_t xcd_remap;        // 1: contiguous wave-block range per XCD
-    int32_t march_max;        // empty-space steps per lane between two shade phases
     float ndc_width, ndc_height, ndc_focal;
-    // ---- camera (CameraSpec, data_spec.hpp:11-22) ----
-    float xf[12];
+    // ---- camera intrinsics (CameraSpec, data_spec.hpp:11-22); poses are per frame ----
     int32_t width, height;
     float fx, fy;
     // ---- options (RenderOptions, render_options.hpp:11-53) ----
@@ -47,11 +61,10 @@ struct KParams {
     int32_t rot_enabled;
     float rot_k[3];
     float rot_cos, rot_sin;
-    // ---- frame / sharding ----
-    uint8_t* rgba;
+    // ---- frames / sharding ----
+    const FrameDesc* frames;     // device table, n_frames entries
+    int32_t n_frames;
     int64_t pitch;
-    const float* depth;
-    float* accum;
     int32_t offscreen;
     int32_t layout;
     int32_t tile_w, tile_h;      // multiples of 8
@@ -60,13 +73,26 @@ struct KParams {
     int32_t n_local_tiles;
     int32_t wblocks_per_tile_x;  // tile_w / 8
     int32_t wblocks_per_tile;    // (tile_w/8)*(tile_h/8)
-    int64_t n_wave_blocks;       // n_local_tiles * wblocks_per_tile
+    int64_t n_wave_blocks;       // per frame: n_local_tiles * wblocks_per_tile
+    uint32_t total_rays;         // n_frames * n_wave_blocks * 64
+    // ---- persistent scheduling ----
+    uint32_t* queue_head;        // device word, reset by prepare_launch_kernel
+    const uint32_t* ray_buf;     // compacted rays (written by raygen_kernel), SoA, stride total_rays
+    uint32_t* ray_buf_rw;
+    const uint32_t* ray_count;   // number of rays in ray_buf
+    uint32_t* ray_count_rw;
+    int32_t basis_words;         // basis_fn words per ray in ray_buf (0 for RGBA)
+    int32_t refill_min;          // refill once this many lanes are idle
+    int32_t march_max;           // march steps per lane between two shade checks
+    int32_t shade_min;           // shade once this many lanes have queued colour work
+    int32_t instrumented;        // any frame carries counters -> FULL flavour
     uint32_t* status;            // device word: bit0 = iteration cap hit
-    unsigned long long* counters;  // optional VrCounters (7 x u64), instrumentation
+    unsigned long long* sched_stats;  // 8 x u64 scheduling tallies (instrumented flavours)
 };
 
 // vr_kernels.hip
-hipError_t launch_render(const KParams& p, int fp_mode, hipStream_t stream);
+hipError_t launch_render(const KParams& p, const FrameTable& tbl, int fp_mode, int n_waves,
+                         hipStream_t stream);
 hipError_t launch_assemble(uint8_t* frame, int64_t pitch, const uint8_t* gathered, int width,
                            int height, int tile_w, int tile_h, int world, hipStream_t stream);
 hipError_t launch_probe(const KParams& p, const float probe[3], float* out_dev,

@@ -19,7 +19,12 @@ namespace vr {
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kWavesPerBlock = 4;
+#ifndef VR_ABLATE
+#define VR_ABLATE 0  // != 0: timing experiments that break the results (never shipped)
+#endif
+#ifndef VR_MIN_WAVES_PER_EU
+#define VR_MIN_WAVES_PER_EU 4
+#endif
 constexpr int kMaxIter = 1 << 22;  // guard against step_size <= 0 (upstream would spin forever)
 
 enum { BASIS_RGBA = -1, BASIS_1 = 1, BASIS_4 = 4, BASIS_9 = 9, BASIS_16 = 16, BASIS_25 = 25 };
@@ -218,7 +223,7 @@ __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, float
     cur.node = node;
     cur.level = l;
     const float cs = u2f((uint32_t)(127 + l + 1) << 23);  // 2^(l+1)
-    *cube_sz = cs;
+    *cube_sz = u2f((uint32_t)(127 - l - 1) << 23);         // 2^-(l+1): x / 2^k == x * 2^-k exactly
     *levels = l + 1;
     *word = w;
     xyz[0] = __builtin_amdgcn_fractf(xyz[0] * cs);
@@ -278,7 +283,13 @@ __device__ __forceinline__ void load_record(const KParams& p, uint32_t leaf, Rec
         const uint4* v = reinterpret_cast<const uint4*>(base);
 #pragma unroll
         for (int j = 0; j < RecTraits<BASIS>::kDwords / 4; ++j) {
+#if VR_ABLATE == 1   // timing experiment only: one 16-byte load per record instead of all
+            const uint4 q = v[0];
+#elif VR_ABLATE == 2  // timing experiment only: no record load at all
+            const uint4 q = make_uint4(leaf + j, leaf, leaf, leaf);
+#else
             const uint4 q = v[j];
+#endif
             r.w[4 * j + 0] = q.x;
             r.w[4 * j + 1] = q.y;
             r.w[4 * j + 2] = q.z;
@@ -335,174 +346,464 @@ __device__ __forceinline__ bool wave_any(bool v) { return __builtin_amdgcn_ballo
 
 // ---------------------------------------------------------------------------
 // render_kernel: render_kernel + trace_ray of the reference
-// (volrend.cu:78-173, rt_core.cuh:66-196).  One wave = one 8x8 pixel block,
-// one lane = one ray.  The march loop is split in two wave-level phases:
-//   march : lanes step through empty space (descent + sigma test, no colour
-//           data) until each has found a sample with sigma > sigma_thresh or
-//           left the volume;
-//   shade : the lanes holding such a sample fetch the SH record, evaluate the
-//           colour and composite -- all of them together.
+// (volrend.cu:78-173, rt_core.cuh:66-196) as a PERSISTENT wave64 kernel.
+//
+//   * The launch covers one or more frames of the same size (a batch of poses);
+//     their rays form one queue: ray id -> (frame, 8x8 pixel block, pixel).
+//   * A fixed number of waves (one 64-thread workgroup each) stays resident.  A wave
+//     takes 64 consecutive ray ids with ONE atomic add on the queue head and sets
+//     them up with all 64 lanes (ray generation is FP64-heavy: never run it on a
+//     few lanes).  Rays that miss the volume are finished on the spot; the rest
+//     are compacted (wave ballot + mbcnt prefix count) into a wave-private LDS
+//     ray cache.  Whenever >= refill_min lanes are idle, the k-th idle lane takes
+//     cache entry next + k.  Terminated rays are replaced in place -- live rays
+//     never move between lanes.
+//   * The colour of a sample never feeds back into the march (only the
+//     attenuation does), so colour evaluation is decoupled from the ray that
+//     produced it.  The wave alternates two phases, each with most lanes busy:
+//       march : descent + sigma test + attenuation / light update / stop test;
+//               samples with sigma > sigma_thresh append a (leaf, weight, owner)
+//               item to a wave-level LDS ring (ballot + mbcnt compaction);
+//       shade : as soon as 64 items wait, every lane takes ONE item -- whoever
+//               owns it -- fetches the SH record, reads the owner's basis from
+//               LDS and evaluates the colour; then each owner adds the results
+//               of its own items, oldest first (the reference's order per ray).
+//   * Finished rays composite over the background, quantise and store their
+//     pixel -- retired and refilled in batches of >= refill_min lanes.
 // Per-ray arithmetic and its order are exactly the reference's.
 // ---------------------------------------------------------------------------
+struct Ray {
+    float cen[3], dir[3], invdir[3];
+    float t, tmax, delta_scale;
+    float light;
+    float out[4];
+    uint32_t xy;       // x | y << 16
+    uint32_t pix_off;  // byte offset of the pixel inside its frame's rgba buffer
+    int frame;
+    bool active;      // lane holds an unfinished ray
+    bool alive;       // still inside `while (t < tmax)`
+    bool entered;     // passed the ray/box test of rt_core.cuh:88
+    bool stopped;     // ended by stop_thresh (renormalised in finish_ray)
+    int iter;
+};
+
+struct PixelRef {
+    int32_t frame, x, y, k, lx, ly;
+    bool in_image;
+};
+
+__device__ __forceinline__ PixelRef locate(const KParams& p, uint32_t id) {
+    PixelRef r;
+    const uint32_t per_frame = (uint32_t)p.n_wave_blocks * 64u;
+    r.frame = (int32_t)(id / per_frame);
+    const uint32_t rid = id - (uint32_t)r.frame * per_frame;
+    const int32_t wb = (int32_t)(rid >> 6);
+    const int32_t lane = (int32_t)(rid & 63u);
+    // wave block -> local tile -> frame tile -> pixel
+    r.k = wb / p.wblocks_per_tile;
+    const int32_t sub = wb - r.k * p.wblocks_per_tile;
+    const int32_t tile = r.k * p.world + p.rank;
+    const int32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    const int32_t sy = sub / p.wblocks_per_tile_x, sx = sub - sy * p.wblocks_per_tile_x;
+    r.lx = sx * 8 + (lane & 7);
+    r.ly = sy * 8 + (lane >> 3);
+    r.x = tx * p.tile_w + r.lx;
+    r.y = ty * p.tile_h + r.ly;
+    r.in_image = r.x < p.width && r.y < p.height;
+    return r;
+}
+
+__device__ __forceinline__ uint8_t* pixel_ptr(const KParams& p, const FrameDesc& fd,
+                                              const PixelRef& r) {
+    if (p.layout == VR_LAYOUT_COMPACT)
+        return fd.rgba + ((int64_t)r.k * p.tile_w * p.tile_h + (int64_t)r.ly * p.tile_w + r.lx) * 4;
+    return fd.rgba + (int64_t)r.y * p.pitch + (int64_t)r.x * 4;
+}
+
+// Ray generation + trace_ray prologue up to the ray/box test
+// (volrend.cu:135-148, rt_core.cuh:74-92).  vdir = (rotated) view direction for the basis.
+template <int FMA>
+__device__ __forceinline__ void setup_ray(const KParams& p, const PixelRef& r, Ray& ray,
+                                          float* vdir) {
+    using P = Policy<FMA>;
+    const FrameDesc& fd = p.frames[r.frame];
+    ray.out[0] = ray.out[1] = ray.out[2] = ray.out[3] = 0.f;
+    ray.light = 1.f;
+    ray.alive = ray.entered = ray.stopped = false;
+    ray.iter = 0;
+    ray.t = 0.f;
+    if (p.N <= 0) return;  // enable_draw = tree.N > 0
+    float dir[3], cen[3];
+    // screen2worlddir, volrend.cu:22-32 (no +0.5 pixel centre offset)
+    float xyz[3];
+    xyz[0] = P::nmadd(0.5f, (float)p.width, (float)r.x) / p.fx;
+    xyz[1] = -(P::nmadd(0.5f, (float)p.height, (float)r.y)) / p.fy;
+    xyz[2] = -1.0f;
+    float xf[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) xf[i] = fd.xf[i];
+    mv3<FMA>(xf, xyz, dir);
+    normalize3<FMA>(dir);
+    cen[0] = xf[9];
+    cen[1] = xf[10];
+    cen[2] = xf[11];
+    vdir[0] = dir[0];
+    vdir[1] = dir[1];
+    vdir[2] = dir[2];
+    if (p.ndc_width > 0) {  // maybe_world2ndc, volrend.cu:34-54
+        const float tt = -(1.f + cen[2]) / dir[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cen[i] = P::madd(tt, dir[i], cen[i]);
+        dir[0] = -((2.f * p.ndc_focal) / p.ndc_width) * (dir[0] / dir[2] - cen[0] / cen[2]);
+        dir[1] = -((2.f * p.ndc_focal) / p.ndc_height) * (dir[1] / dir[2] - cen[1] / cen[2]);
+        dir[2] = -2.f / cen[2];
+        cen[0] = -((2.f * p.ndc_focal) / p.ndc_width) * (cen[0] / cen[2]);
+        cen[1] = -((2.f * p.ndc_focal) / p.ndc_height) * (cen[1] / cen[2]);
+        cen[2] = 1.f + 2.f / cen[2];
+        normalize3<FMA>(dir);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cen[i] = P::madd(p.scale[i], cen[i], p.offset[i]);
+
+    float tmax_bg = 1e9f;
+    if (!p.offscreen && fd.depth) tmax_bg = fd.depth[(int64_t)r.y * p.width + r.x];
+
+    if (p.rot_enabled) {  // rodrigues, volrend.cu:57-71 (uniform part done on host)
+        float cr[3];
+        cross3<FMA>(p.rot_k, vdir, cr);
+        const float dot = dot3<FMA>(p.rot_k, vdir);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float a = P::madd(vdir[i], p.rot_cos, cr[i] * p.rot_sin);
+            const double kd = (double)(p.rot_k[i] * dot);
+            const double om = 1.0 - (double)p.rot_cos;
+            vdir[i] = (float)P::dmadd(kd, om, (double)a);
+        }
+    }
+    // _get_delta_scale, rt_core.cuh:52-63
+    dir[0] *= p.scale[0];
+    dir[1] *= p.scale[1];
+    dir[2] *= p.scale[2];
+    const float delta_scale = 1.f / norm3<FMA>(dir);
+    dir[0] *= delta_scale;
+    dir[1] *= delta_scale;
+    dir[2] *= delta_scale;
+    tmax_bg /= delta_scale;
+    float invdir[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) invdir[i] = (float)(1.0 / ((double)dir[i] + 1e-9));
+    // _dda_world, rt_core.cuh:18-34: the 1e-6 literals make this FP64
+    float tmin = 0.0f, tmax = 1e4f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float t1 = (float)((((double)p.bbox[i] + 1e-6) - (double)cen[i]) * (double)invdir[i]);
+        const float t2 =
+            (float)((((double)p.bbox[i + 3] - 1e-6) - (double)cen[i]) * (double)invdir[i]);
+        tmin = vmax(tmin, vmin(t1, t2));
+        tmax = vmin(tmax, vmax(t1, t2));
+    }
+    tmax = vmin(tmax, tmax_bg);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ray.cen[i] = cen[i];
+        ray.dir[i] = dir[i];
+        ray.invdir[i] = invdir[i];
+    }
+    ray.delta_scale = delta_scale;
+    ray.tmax = tmax;
+    if (tmax < 0 || tmin > tmax) {
+        if (p.render_depth) ray.out[3] = 1.f;  // ray misses the box, rt_core.cuh:88-92
+        return;
+    }
+    ray.entered = true;
+    ray.t = tmin;
+    ray.alive = tmin < tmax;
+}
+
+// End of trace_ray + the compositing tail of render_kernel (rt_core.cuh:176-194,
+// volrend.cu:152-172): early-stop renormalisation / final alpha, optional debug
+// outputs, composite, quantise, store.
+template <int FMA, bool COUNT>
+__device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const RayCounters& rc) {
+    using P = Policy<FMA>;
+    const FrameDesc& fd = p.frames[ray.frame];
+    float* out = ray.out;
+    if (ray.stopped) {  // rt_core.cuh:176-185, applied once every queued colour has landed
+        if (p.render_depth) out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
+        const float scale = 1.f / (1.f - ray.light);
+        out[0] *= scale;
+        out[1] *= scale;
+        out[2] *= scale;
+        out[3] = 1.f;
+    } else if (ray.entered) {  // rt_core.cuh:189-194
+        if (p.render_depth) {
+            out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
+            out[3] = 1.f;
+        } else {
+            out[3] = 1.f - ray.light;
+        }
+    }
+    if (COUNT && fd.counters) {
+        // VrCounters: rays, rays_hit_box, samples, child_reads, hit_samples, alg_bytes,
+        // early_stops.  alg_bytes per SURVEY.md 8(d):
+        //   sum over samples (4*L + 2 + hit*2*(data_dim-1)) + 4 per pixel
+        const unsigned long long bytes = 4ull * rc.child_reads + 2ull * rc.samples +
+                                         2ull * (unsigned long long)(p.data_dim - 1) * rc.hits +
+                                         4ull;
+        if (p.N > 0) atomicAdd(&fd.counters[0], 1ull);
+        atomicAdd(&fd.counters[1], ray.entered ? 1ull : 0ull);
+        atomicAdd(&fd.counters[2], (unsigned long long)rc.samples);
+        atomicAdd(&fd.counters[3], (unsigned long long)rc.child_reads);
+        atomicAdd(&fd.counters[4], (unsigned long long)rc.hits);
+        atomicAdd(&fd.counters[5], bytes);
+        atomicAdd(&fd.counters[6], (unsigned long long)rc.early);
+    }
+    const int32_t x = (int32_t)(ray.xy & 0xFFFFu), y = (int32_t)(ray.xy >> 16);
+    const int64_t pix = (int64_t)y * p.width + x;
+    if (fd.accum)
+        reinterpret_cast<float4*>(fd.accum)[pix] = make_float4(out[0], out[1], out[2], out[3]);
+    uint8_t* px = fd.rgba + ray.pix_off;
+    // composite, volrend.cu:152-172
+    const float nalpha = 1.f - out[3];
+    if (p.offscreen) {
+        out[0] = P::madd(p.background_brightness, nalpha, out[0]);
+        out[1] = P::madd(p.background_brightness, nalpha, out[1]);
+        out[2] = P::madd(p.background_brightness, nalpha, out[2]);
+    } else {
+        const uint32_t init = *reinterpret_cast<const uint32_t*>(px);
+        out[0] = P::madd((float)(init & 0xFFu) / 255.f, nalpha, out[0]);
+        out[1] = P::madd((float)((init >> 8) & 0xFFu) / 255.f, nalpha, out[1]);
+        out[2] = P::madd((float)((init >> 16) & 0xFFu) / 255.f, nalpha, out[2]);
+    }
+    *reinterpret_cast<uint32_t*>(px) =
+        quant8(out[0]) | (quant8(out[1]) << 8) | (quant8(out[2]) << 16) | 0xFF000000u;
+}
+
+// ---------------------------------------------------------------------------
+// Ray buffer (global memory, written by raygen_kernel, structure of arrays: field
+// f of ray r at word f*capacity + r):
+//   0-2 cen, 3-5 dir, 6-8 invdir, 9 t, 10 tmax, 11 delta_scale, 12 xy,
+//   13 pix_off, 14 frame, 15.. basis_fn[0..nb)
+// Wave-private LDS of the march kernel (one wave per workgroup):
+//   btab : basis_fn[i] of the ray currently held by lane l at word i*64 + l
+//   ring : colour work items (leaf, weight, owner lane) in sample order, and the
+//          three colour contributions computed for each of them
+// ---------------------------------------------------------------------------
+constexpr int kRayWords = 15;
+constexpr int kRing = 128;   // capacity; at most 127 items are ever outstanding
+constexpr int kOwnerQ = 4;   // outstanding items per ray (8-bit ring positions in one VGPR)
+
 template <int FMA, int BASIS, int MODE>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void render_kernel(const KParams p) {
+__global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(const KParams p) {
     using P = Policy<FMA>;
     constexpr bool N2 = MODE != MODE_GENERIC;
     constexpr bool LOBES = MODE != MODE_FAST;
     constexpr bool COUNT = MODE != MODE_FAST;
+    constexpr int NB = BASIS > 1 ? BASIS : 1;
+    constexpr bool HAS_BASIS = BASIS != BASIS_RGBA;
+    __shared__ float btab[(HAS_BASIS ? NB : 1) * kWave];
+    __shared__ uint32_t it_leaf[kRing];
+    __shared__ float it_w[kRing];
+    __shared__ uint32_t it_own[kRing];
+    __shared__ float res[3 * kRing];
 
     const int lane = threadIdx.x & (kWave - 1);
-    int64_t wb = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (p.xcd_remap) {
-        // blocks are dealt round-robin to the 8 XCDs (each with a private L2): give
-        // every XCD one contiguous run of wave blocks = one screen region
-        const int64_t nb = gridDim.x;
-        const int64_t b = blockIdx.x;
-        const int64_t per = nb / 8, rem = nb % 8;
-        const int64_t xcd = b % 8, j = b / 8;
-        const int64_t logical = xcd * per + (xcd < rem ? xcd : rem) + j;
-        wb = logical * kWavesPerBlock + (threadIdx.x >> 6);
-    }
-    if (wb >= p.n_wave_blocks) return;
-    // wave block -> local tile -> frame tile -> pixel
-    const int32_t k = (int32_t)(wb / p.wblocks_per_tile);
-    const int32_t sub = (int32_t)(wb - (int64_t)k * p.wblocks_per_tile);
-    const int32_t tile = k * p.world + p.rank;
-    const int32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-    const int32_t sy = sub / p.wblocks_per_tile_x, sx = sub - sy * p.wblocks_per_tile_x;
-    const int32_t lx = sx * 8 + (lane & 7), ly = sy * 8 + (lane >> 3);  // within tile
-    const int32_t x = tx * p.tile_w + lx, y = ty * p.tile_h + ly;
-    const bool in_image = x < p.width && y < p.height;
-
-    uint8_t* px = nullptr;
-    int64_t pix = 0;
-    uint32_t init = 0;
-    if (in_image) {
-        if (p.layout == VR_LAYOUT_COMPACT)
-            px = p.rgba + ((int64_t)k * p.tile_w * p.tile_h + (int64_t)ly * p.tile_w + lx) * 4;
-        else
-            px = p.rgba + (int64_t)y * p.pitch + (int64_t)x * 4;
-        pix = (int64_t)y * p.width + x;
-        if (!p.offscreen) init = *reinterpret_cast<const uint32_t*>(px);
-    }
-
-    // The probe circle (volrend.cu:100-134) is drawn by probe_overlay_kernel after this
-    // kernel: circle pixels end with out[3]=1, i.e. they do not depend on anything here.
-    float dir[3] = {0.f, 0.f, 1.f}, cen[3] = {0.f, 0.f, 0.f}, vdir[3];
-    float out[4] = {0.f, 0.f, 0.f, 0.f};
-    float t = 0.f, tmax = -1.f, delta_scale = 1.f;
-    float invdir[3] = {1.f, 1.f, 1.f};
-    bool alive = false;    // still inside `while (t < tmax)`
-    bool entered = false;  // passed the ray/box test of rt_core.cuh:88
-    if (in_image && p.N > 0) {
-        // screen2worlddir, volrend.cu:22-32 (no +0.5 pixel centre offset)
-        float xyz[3];
-        xyz[0] = P::nmadd(0.5f, (float)p.width, (float)x) / p.fx;
-        xyz[1] = -(P::nmadd(0.5f, (float)p.height, (float)y)) / p.fy;
-        xyz[2] = -1.0f;
-        mv3<FMA>(p.xf, xyz, dir);
-        normalize3<FMA>(dir);
-        cen[0] = p.xf[9];
-        cen[1] = p.xf[10];
-        cen[2] = p.xf[11];
-        vdir[0] = dir[0];
-        vdir[1] = dir[1];
-        vdir[2] = dir[2];
-
-        if (p.ndc_width > 0) {  // maybe_world2ndc, volrend.cu:34-54
-            const float tt = -(1.f + cen[2]) / dir[2];
+    Ray ray;
+    ray.active = false;
+    ray.alive = ray.entered = ray.stopped = false;
+    ray.frame = 0;
+    ray.xy = 0;
+    ray.pix_off = 0;
+    ray.iter = 0;
+    ray.t = 0.f;
+    ray.tmax = -1.f;
+    ray.light = 1.f;
+    ray.delta_scale = 1.f;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) cen[i] = P::madd(tt, dir[i], cen[i]);
-            dir[0] = -((2.f * p.ndc_focal) / p.ndc_width) * (dir[0] / dir[2] - cen[0] / cen[2]);
-            dir[1] = -((2.f * p.ndc_focal) / p.ndc_height) * (dir[1] / dir[2] - cen[1] / cen[2]);
-            dir[2] = -2.f / cen[2];
-            cen[0] = -((2.f * p.ndc_focal) / p.ndc_width) * (cen[0] / cen[2]);
-            cen[1] = -((2.f * p.ndc_focal) / p.ndc_height) * (cen[1] / cen[2]);
-            cen[2] = 1.f + 2.f / cen[2];
-            normalize3<FMA>(dir);
+    for (int i = 0; i < 3; ++i) {
+        ray.cen[i] = 0.f;
+        ray.dir[i] = 0.f;
+        ray.invdir[i] = 1.f;
+    }
+    ray.out[0] = ray.out[1] = ray.out[2] = ray.out[3] = 0.f;
+    RayCounters rc;
+    Cursor cur;
+    uint32_t qpos = 0;  // up to kOwnerQ ring positions (8 bits each), oldest in the low byte
+    int qn = 0;
+    // wave-uniform scheduler state
+    bool exhausted = false;  // the ray buffer has been handed out completely
+    uint32_t chunk_next = 0, chunk_end = 0;  // this wave's private range of ray ids
+    uint32_t ring_head = 0, ring_tail = 0;  // items [head, tail) are waiting for a shader lane
+    const uint32_t total = *p.ray_count;  // rays that entered the volume (raygen_kernel)
+    const uint32_t cap = p.total_rays;     // field stride of the ray buffer
+    // scheduling statistics (instrumented flavours only): rounds and busy lanes per phase
+    uint32_t st_march_r = 0, st_march_l = 0, st_shade_r = 0, st_shade_l = 0, st_fill = 0,
+             st_fin_r = 0, st_fin_l = 0, st_iter = 0;
+
+    // Colour evaluation of up to 64 queued items, one per lane, whoever owns them;
+    // afterwards every owner adds the contributions of its own items, oldest first
+    // (= the reference's accumulation order, rt_core.cuh:161).
+    auto shade_chunk = [&](int n) {
+        __syncthreads();  // item pushes are visible
+        if (COUNT) {
+            st_shade_r++;
+            st_shade_l += (uint32_t)n;
         }
+        if (lane < n) {
+            const uint32_t j = (ring_head + (uint32_t)lane) & (kRing - 1);
+            const float weight = it_w[j];
+            const uint32_t own = it_own[j];
+            Record<BASIS> rec;
+            load_record<BASIS>(p, it_leaf[j], rec);
+            if (HAS_BASIS) {
+                float b[NB];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) cen[i] = P::madd(p.scale[i], cen[i], p.offset[i]);
-
-        float tmax_bg = 1e9f;
-        if (!p.offscreen && p.depth) tmax_bg = p.depth[pix];
-
-        if (p.rot_enabled) {  // rodrigues, volrend.cu:57-71 (uniform part done on host)
-            float cr[3];
-            cross3<FMA>(p.rot_k, vdir, cr);
-            const float dot = dot3<FMA>(p.rot_k, vdir);
+                for (int i = 0; i < NB; ++i) b[i] = btab[i * kWave + own];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const float a = P::madd(vdir[i], p.rot_cos, cr[i] * p.rot_sin);
-                const double kd = (double)(p.rot_k[i] * dot);
-                const double om = 1.0 - (double)p.rot_cos;
-                vdir[i] = (float)P::dmadd(kd, om, (double)a);
+                for (int c = 0; c < 3; ++c) {
+#if VR_ABLATE == 3   // timing experiment only: loads kept, SH / sigmoid arithmetic removed
+                    uint32_t x = 0;
+                    for (int i = 0; i < RecTraits<BASIS>::kDwords; ++i) x ^= rec.w[i];
+                    res[c * kRing + j] = weight * u2f((x & 0x007FFFFFu) | 0x3F000000u) * b[c];
+#else
+                    const float tmp = channel_dot<FMA, BASIS>(b, rec, c);
+                    res[c * kRing + j] = weight / (1.f + vr_expf(-tmp));
+#endif
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) res[c * kRing + j] = rec.at(c);
+                // RGBA: out[c] = madd(colour, weight, out[c]) is formed by the owner
             }
         }
-
-        // ---- trace_ray prologue, rt_core.cuh:74-92 ----
-        // _get_delta_scale, rt_core.cuh:52-63
-        dir[0] *= p.scale[0];
-        dir[1] *= p.scale[1];
-        dir[2] *= p.scale[2];
-        delta_scale = 1.f / norm3<FMA>(dir);
-        dir[0] *= delta_scale;
-        dir[1] *= delta_scale;
-        dir[2] *= delta_scale;
-        tmax_bg /= delta_scale;
+        __syncthreads();  // contributions are visible
+        const uint32_t head8 = ring_head & 0xFFu;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) invdir[i] = (float)(1.0 / ((double)dir[i] + 1e-9));
-        // _dda_world, rt_core.cuh:18-34: the 1e-6 literals make this FP64
-        float tmin = 0.0f;
-        tmax = 1e4f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float t1 =
-                (float)((((double)p.bbox[i] + 1e-6) - (double)cen[i]) * (double)invdir[i]);
-            const float t2 =
-                (float)((((double)p.bbox[i + 3] - 1e-6) - (double)cen[i]) * (double)invdir[i]);
-            tmin = vmax(tmin, vmin(t1, t2));
-            tmax = vmin(tmax, vmax(t1, t2));
+        for (int d = 0; d < kOwnerQ; ++d) {
+            if (qn > 0 && (((qpos & 0xFFu) - head8) & 0xFFu) < (uint32_t)n) {
+                const uint32_t j = qpos & (kRing - 1);
+                if (HAS_BASIS) {
+                    ray.out[0] += res[0 * kRing + j];
+                    ray.out[1] += res[1 * kRing + j];
+                    ray.out[2] += res[2 * kRing + j];
+                } else {
+                    const float weight = it_w[j];
+                    ray.out[0] = P::madd(res[0 * kRing + j], weight, ray.out[0]);
+                    ray.out[1] = P::madd(res[1 * kRing + j], weight, ray.out[1]);
+                    ray.out[2] = P::madd(res[2 * kRing + j], weight, ray.out[2]);
+                }
+                qpos >>= 8;
+                --qn;
+            }
         }
-        tmax = vmin(tmax, tmax_bg);
-        if (tmax < 0 || tmin > tmax) {
-            if (p.render_depth) out[3] = 1.f;  // ray misses the box
-        } else {
-            entered = true;
-            t = tmin;
-            alive = t < tmax;
-        }
-    }
+        ring_head += (uint32_t)n;
+    };
 
-    RayCounters rc;
-
-    float basis_fn[VR_MAX_BASIS];
-#pragma unroll
-    for (int i = 0; i < VR_MAX_BASIS; ++i) basis_fn[i] = 0.f;
-    if (BASIS != BASIS_RGBA && wave_any(alive)) {
-        precalc_basis<FMA, LOBES>(p, vdir, basis_fn);
-#pragma unroll
-        for (int i = 0; i < VR_MAX_BASIS; ++i)
-            if (i < p.basis_min || i > p.basis_max) basis_fn[i] = 0.f;
-    }
-
-    float light = 1.f;
-    bool stopped = false;  // ended by stop_thresh (out[3] already final)
-    Cursor cur;
-    int iter = 0;
-    // ---- march / shade loop, rt_core.cuh:108-188 ----
     for (;;) {
-        bool pend = false;
-        uint32_t leaf = 0;
-        float delta_t = 0.f, sigma = 0.f;
-        // march: up to march_max steps, or until every live lane holds a sample to
-        // shade (or died)
-        for (int m = 0; m < p.march_max && wave_any(alive && !pend); ++m) {
-            if (alive && !pend) {
+        // ---- retire finished rays and hand their lanes new ones, in batches ----
+        const bool done = ray.active && !ray.alive && qn == 0;
+        const unsigned long long m_done = __builtin_amdgcn_ballot_w64(done);
+        const unsigned long long m_free = __builtin_amdgcn_ballot_w64(!ray.active);
+        const unsigned long long m_busy =
+            __builtin_amdgcn_ballot_w64(ray.active && (ray.alive || qn > 0));
+        const int n_avail = __builtin_popcountll(m_done | m_free);
+        if (COUNT) st_iter++;
+        if (n_avail > 0 && (m_busy == 0ull || (!exhausted && n_avail >= p.refill_min))) {
+            if (COUNT && m_done != 0ull) {
+                st_fin_r++;
+                st_fin_l += (uint32_t)__builtin_popcountll(m_done);
+            }
+            if (done) {
+                finish_ray<FMA, COUNT>(p, ray, rc);
+                ray.active = false;
+            }
+            // Idle lanes take consecutive rays from the buffer.  The wave owns a private
+            // chunk [chunk_next, chunk_end) of ray ids and only goes to the global queue
+            // head (ONE returning atomic -- a single word sustains ~90 of them per
+            // microsecond chip-wide) when the chunk is used up; chunk sizes shrink as the
+            // queue drains (guided self-scheduling) so the tail stays balanced.
+            if (!exhausted && chunk_next >= chunk_end) {
+                uint32_t base = 0, size = 0;
+                if (lane == 0) {
+                    const uint32_t seen =
+                        __hip_atomic_load(p.queue_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t remaining = seen < total ? total - seen : 0u;
+                    size = remaining / (2u * gridDim.x);
+                    size = size < 64u ? 64u : (size > 4096u ? 4096u : size);
+                    size &= ~63u;
+                    base = atomicAdd(p.queue_head, size);
+                }
+                base = __builtin_amdgcn_readfirstlane(base);
+                size = __builtin_amdgcn_readfirstlane(size);
+                if (base >= total) {
+                    exhausted = true;
+                } else {
+                    chunk_next = base;
+                    chunk_end = base + size < total ? base + size : total;
+                }
+            }
+            if (!exhausted) {
+                const unsigned long long idle = m_done | m_free;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
+                    (uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const uint32_t r = chunk_next + rank;
+                const uint32_t c_end = chunk_end;
+                const uint32_t left = chunk_end - chunk_next;
+                chunk_next += (uint32_t)n_avail < left ? (uint32_t)n_avail : left;
+                if (!ray.active) {
+                    if (r < c_end) {
+                        const uint32_t* rb = p.ray_buf + r;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            ray.cen[i] = u2f(rb[(size_t)(0 + i) * cap]);
+                            ray.dir[i] = u2f(rb[(size_t)(3 + i) * cap]);
+                            ray.invdir[i] = u2f(rb[(size_t)(6 + i) * cap]);
+                        }
+                        ray.t = u2f(rb[(size_t)9 * cap]);
+                        ray.tmax = u2f(rb[(size_t)10 * cap]);
+                        ray.delta_scale = u2f(rb[(size_t)11 * cap]);
+                        ray.xy = rb[(size_t)12 * cap];
+                        ray.pix_off = rb[(size_t)13 * cap];
+                        ray.frame = (int)rb[(size_t)14 * cap];
+                        if (HAS_BASIS) {
+#pragma unroll
+                            for (int i = 0; i < NB; ++i)
+                                btab[i * kWave + lane] = u2f(rb[(size_t)(kRayWords + i) * cap]);
+                        }
+                        ray.out[0] = ray.out[1] = ray.out[2] = ray.out[3] = 0.f;
+                        ray.light = 1.f;
+                        ray.active = ray.alive = ray.entered = true;
+                        ray.stopped = false;
+                        ray.iter = 0;
+                        rc = RayCounters();
+                        cur = Cursor();
+                        qn = 0;
+                        qpos = 0;
+                    }
+                }
+            }
+        }
+        if (!wave_any(ray.active)) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- march: lanes with a live ray and room for another outstanding item ----
+        for (int m = 0; m < p.march_max; ++m) {
+            const bool go = ray.active && ray.alive && qn < kOwnerQ;
+            if (!wave_any(go)) break;
+            if (COUNT) {
+                st_march_r++;
+                st_march_l += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(go));
+            }
+            bool push = false;
+            uint32_t leaf = 0;
+            float weight = 0.f;
+            if (go) {
                 float pos[3];
-                pos[0] = P::madd(t, dir[0], cen[0]);
-                pos[1] = P::madd(t, dir[1], cen[1]);
-                pos[2] = P::madd(t, dir[2], cen[2]);
+                pos[0] = P::madd(ray.t, ray.dir[0], ray.cen[0]);
+                pos[1] = P::madd(ray.t, ray.dir[1], ray.cen[1]);
+                pos[2] = P::madd(ray.t, ray.dir[2], ray.cen[2]);
                 float cube_sz;
                 int levels;
                 uint32_t word;
@@ -515,104 +816,174 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void render_kernel(const KPa
                     rc.samples++;
                     rc.child_reads += (uint32_t)levels;
                 }
-                const float t_subcube = dda_unit<FMA>(pos, invdir) / cube_sz;
-                delta_t = t_subcube + p.step_size;
-                sigma = h2f((uint16_t)(word & 0xFFFFu));
+                // rt_core.cuh:116: dda / cube_sz.  For N == 2 cube_sz is a power of two and
+                // query_n2 hands back its reciprocal: the product is the same real number
+                // rounded once, i.e. bit-identical to the IEEE division.
+                const float dda = dda_unit<FMA>(pos, ray.invdir);
+                const float t_subcube = N2 ? dda * cube_sz : dda / cube_sz;
+                const float delta_t = t_subcube + p.step_size;
+                const float sigma = h2f((uint16_t)(word & 0xFFFFu));
+                bool stop = false;
                 if (sigma > p.sigma_thresh) {
-                    pend = true;
+                    // rt_core.cuh:118-121,174: attenuation, weight and the light update are
+                    // taken now; the colour of this sample -- which nothing else depends on --
+                    // becomes a work item for the shade phase.
+                    if (COUNT) rc.hits++;
+                    const float att = vr_expf(-delta_t * ray.delta_scale * sigma);
+                    weight = ray.light * (1.f - att);
+                    if (p.render_depth)
+                        ray.out[0] = P::madd(weight, ray.t, ray.out[0]);
+                    else
+                        push = true;
+                    ray.light *= att;
+                    stop = ray.light < p.stop_thresh;
+                }
+                if (stop) {
+                    ray.stopped = true;
+                    ray.alive = false;
+                    if (COUNT) rc.early++;
                 } else {
-                    t += delta_t;
-                    alive = t < tmax;
-                    if (++iter >= kMaxIter) {
-                        alive = false;
+                    ray.t += delta_t;
+                    ray.alive = ray.t < ray.tmax;
+                    if (++ray.iter >= kMaxIter) {
+                        ray.alive = false;
                         if (p.status) atomicOr(p.status, 1u);
                     }
                 }
             }
-        }
-        if (!wave_any(pend)) {
-            if (!wave_any(alive)) break;
-            continue;
-        }
-        if (pend) {
-            if (COUNT) rc.hits++;
-            const float att = vr_expf(-delta_t * delta_scale * sigma);
-            const float weight = light * (1.f - att);
-            if (p.render_depth) {
-                out[0] = P::madd(weight, t, out[0]);
-            } else {
-                Record<BASIS> rec;
-                load_record<BASIS>(p, leaf, rec);
-                if (BASIS != BASIS_RGBA) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float tmp = channel_dot<FMA, BASIS>(basis_fn, rec, c);
-                        out[c] += weight / (1.f + vr_expf(-tmp));
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) out[c] = P::madd(rec.at(c), weight, out[c]);
+            // append this step's items to the ring: k-th pushing lane -> tail + k
+            const unsigned long long m_push = __builtin_amdgcn_ballot_w64(push);
+            if (m_push != 0ull) {
+                if (push) {
+                    const uint32_t seq =
+                        ring_tail + __builtin_amdgcn_mbcnt_hi(
+                                        (uint32_t)(m_push >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m_push, 0u));
+                    const uint32_t j = seq & (kRing - 1);
+                    it_leaf[j] = leaf;
+                    it_w[j] = weight;
+                    it_own[j] = (uint32_t)lane;
+                    qpos |= (seq & 0xFFu) << (8 * qn);
+                    ++qn;
                 }
-            }
-            light *= att;
-            if (light < p.stop_thresh) {
-                if (p.render_depth) out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
-                const float scale = 1.f / (1.f - light);
-                out[0] *= scale;
-                out[1] *= scale;
-                out[2] *= scale;
-                out[3] = 1.f;
-                stopped = true;
-                alive = false;
-                if (COUNT) rc.early++;
-            } else {
-                t += delta_t;
-                alive = t < tmax;
-                if (++iter >= kMaxIter) {
-                    alive = false;
-                    if (p.status) atomicOr(p.status, 1u);
-                }
+                ring_tail += (uint32_t)__builtin_popcountll(m_push);
+                if (ring_tail - ring_head >= (uint32_t)kWave) shade_chunk(kWave);
             }
         }
+        // nobody can march any more (queues full / rays ended): flush what is queued
+        if (ring_tail != ring_head && !wave_any(ray.active && ray.alive && qn < kOwnerQ))
+            shade_chunk((int)(ring_tail - ring_head));
     }
-    if (!in_image) return;
-    if (entered && !stopped) {  // rt_core.cuh:189-194
-        if (p.render_depth) {
-            out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
-            out[3] = 1.f;
-        } else {
-            out[3] = 1.f - light;
+    if (COUNT && p.sched_stats && lane == 0) {
+        atomicAdd(&p.sched_stats[0], (unsigned long long)st_march_r);
+        atomicAdd(&p.sched_stats[1], (unsigned long long)st_march_l);
+        atomicAdd(&p.sched_stats[2], (unsigned long long)st_shade_r);
+        atomicAdd(&p.sched_stats[3], (unsigned long long)st_shade_l);
+        atomicAdd(&p.sched_stats[4], (unsigned long long)st_fill);
+        atomicAdd(&p.sched_stats[5], (unsigned long long)st_fin_r);
+        atomicAdd(&p.sched_stats[6], (unsigned long long)st_fin_l);
+        atomicAdd(&p.sched_stats[7], (unsigned long long)st_iter);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// raygen_kernel: one lane per pixel of every frame of the launch, at full occupancy.
+// Ray generation, NDC warp, world->tree transform, view-direction rotation and the
+// ray/box test (volrend.cu:135-148, rt_core.cuh:74-92) with their FP64 islands,
+// plus the basis of the view direction (rt_core.cuh:96-103).  Rays that miss the
+// volume are composited and stored right here; the others are appended to the
+// ray buffer -- each wave compacts its survivors with a ballot / mbcnt prefix
+// count and reserves their slots with ONE atomic.
+// ---------------------------------------------------------------------------
+constexpr int kGenWaves = 16;  // waves (8x8 pixel blocks) per raygen workgroup
+
+template <int FMA, bool FULL>
+__global__ __launch_bounds__(kWave* kGenWaves) void raygen_kernel(const KParams p) {
+    __shared__ uint32_t wave_count[kGenWaves];
+    __shared__ uint32_t wave_base[kGenWaves];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const uint32_t id =
+        (uint32_t)(((int64_t)blockIdx.x * kGenWaves + wave) * kWave + lane);
+    bool valid = false;
+    Ray nr;
+    float vdir[3] = {0.f, 0.f, 1.f};
+    if (id < p.total_rays) {
+        const PixelRef r = locate(p, id);
+        if (r.in_image) {
+            nr.frame = r.frame;
+            nr.xy = (uint32_t)r.x | ((uint32_t)r.y << 16);
+            nr.pix_off =
+                (uint32_t)(pixel_ptr(p, p.frames[r.frame], r) - p.frames[r.frame].rgba);
+            setup_ray<FMA>(p, r, nr, vdir);
+            if (nr.alive) {
+                valid = true;
+            } else {
+                RayCounters z;  // a ray without a single sample
+                finish_ray<FMA, FULL>(p, nr, z);
+            }
         }
     }
-    if (COUNT && p.counters) {
-        // VrCounters: rays, rays_hit_box, samples, child_reads, hit_samples, alg_bytes,
-        // early_stops.  alg_bytes per SURVEY.md 8(d):
-        //   sum over samples (4*L + 2 + hit*2*(data_dim-1)) + 4 per pixel
-        const unsigned long long bytes = 4ull * rc.child_reads + 2ull * rc.samples +
-                                         2ull * (unsigned long long)(p.data_dim - 1) * rc.hits +
-                                         4ull;
-        if (p.N > 0) atomicAdd(&p.counters[0], 1ull);
-        atomicAdd(&p.counters[1], entered ? 1ull : 0ull);
-        atomicAdd(&p.counters[2], (unsigned long long)rc.samples);
-        atomicAdd(&p.counters[3], (unsigned long long)rc.child_reads);
-        atomicAdd(&p.counters[4], (unsigned long long)rc.hits);
-        atomicAdd(&p.counters[5], bytes);
-        atomicAdd(&p.counters[6], (unsigned long long)rc.early);
+    // Compaction: wave ballot + mbcnt prefix inside the wave, a 16-entry scan over the
+    // workgroup's waves, and ONE atomic per workgroup on the ray counter (a single
+    // word only sustains ~90 returning atomics per microsecond chip-wide).
+    const unsigned long long m_valid = __builtin_amdgcn_ballot_w64(valid);
+    if (lane == 0) wave_count[wave] = (uint32_t)__builtin_popcountll(m_valid);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < kGenWaves; ++w) {
+            wave_base[w] = sum;
+            sum += wave_count[w];
+        }
+        const uint32_t base = sum ? atomicAdd(p.ray_count_rw, sum) : 0u;
+#pragma unroll
+        for (int w = 0; w < kGenWaves; ++w) wave_base[w] += base;
     }
-    if (p.accum) reinterpret_cast<float4*>(p.accum)[pix] = make_float4(out[0], out[1], out[2], out[3]);
-    // composite, volrend.cu:152-172
-    const float nalpha = 1.f - out[3];
-    if (p.offscreen) {
-        out[0] = P::madd(p.background_brightness, nalpha, out[0]);
-        out[1] = P::madd(p.background_brightness, nalpha, out[1]);
-        out[2] = P::madd(p.background_brightness, nalpha, out[2]);
-    } else {
-        out[0] = P::madd((float)(init & 0xFFu) / 255.f, nalpha, out[0]);
-        out[1] = P::madd((float)((init >> 8) & 0xFFu) / 255.f, nalpha, out[1]);
-        out[2] = P::madd((float)((init >> 16) & 0xFFu) / 255.f, nalpha, out[2]);
+    __syncthreads();
+    if (!valid) return;
+    const uint32_t slot =
+        wave_base[wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_valid >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m_valid, 0u));
+    const size_t cap = p.total_rays;
+    uint32_t* rb = p.ray_buf_rw + slot;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        rb[(size_t)(0 + i) * cap] = f2u(nr.cen[i]);
+        rb[(size_t)(3 + i) * cap] = f2u(nr.dir[i]);
+        rb[(size_t)(6 + i) * cap] = f2u(nr.invdir[i]);
     }
-    *reinterpret_cast<uint32_t*>(px) =
-        quant8(out[0]) | (quant8(out[1]) << 8) | (quant8(out[2]) << 16) | 0xFF000000u;
+    rb[(size_t)9 * cap] = f2u(nr.t);
+    rb[(size_t)10 * cap] = f2u(nr.tmax);
+    rb[(size_t)11 * cap] = f2u(nr.delta_scale);
+    rb[(size_t)12 * cap] = nr.xy;
+    rb[(size_t)13 * cap] = nr.pix_off;
+    rb[(size_t)14 * cap] = (uint32_t)nr.frame;
+    if (p.basis_words > 0) {
+        // rt_core.cuh:96-103: basis of the view direction, zeroed outside basis_minmax
+        float b[VR_MAX_BASIS];
+#pragma unroll
+        for (int i = 0; i < VR_MAX_BASIS; ++i) b[i] = 0.f;
+        precalc_basis<FMA, FULL>(p, vdir, b);
+#pragma unroll
+        for (int i = 0; i < VR_MAX_BASIS; ++i)
+            if (i < p.basis_words)
+                rb[(size_t)(kRayWords + i) * cap] =
+                    f2u((i < p.basis_min || i > p.basis_max) ? 0.f : b[i]);
+    }
+}
+
+// Writes the per-launch frame table into device memory and resets the ray queue.
+// (Stream-ordered replacement for a pinned-memory H2D copy + memset.)
+__global__ void prepare_launch_kernel(FrameTable tbl, FrameDesc* frames, uint32_t* queue_head,
+                                      uint32_t* ray_count) {
+    const int i = threadIdx.x;
+    if (i < tbl.n) frames[i] = tbl.f[i];
+    if (i == 0) {
+        *queue_head = 0u;
+        *ray_count = 0u;
+    }
 }
 
 // Probe circle overlay, volrend.cu:100-134.  Pixels inside the circle skip the
@@ -644,7 +1015,9 @@ __global__ void probe_overlay_kernel(const KParams p) {
 #pragma unroll
         for (int i = 0; i < VR_MAX_BASIS; ++i) basis_fn[i] = 0.f;
         cen[2] = -__builtin_sqrtf(1 - c);
-        mv3<FMA>(p.xf, cen, dir);
+        float xf[9];
+        for (int i = 0; i < 9; ++i) xf[i] = p.frames[blockIdx.y].xf[i];
+        mv3<FMA>(xf, cen, dir);
         precalc_basis<FMA, true>(p, dir, basis_fn);
         // upstream indexes past basis_dim with the default basis_minmax {0,24} (UB);
         // like the oracle, clamp to the coefficients that exist
@@ -662,15 +1035,16 @@ __global__ void probe_overlay_kernel(const KParams p) {
     }
     out[3] = 1.f;
     const int64_t pix = (int64_t)y * p.width + x;
-    if (p.accum) reinterpret_cast<float4*>(p.accum)[pix] = make_float4(out[0], out[1], out[2], out[3]);
+    const FrameDesc& fd = p.frames[blockIdx.y];
+    if (fd.accum) reinterpret_cast<float4*>(fd.accum)[pix] = make_float4(out[0], out[1], out[2], out[3]);
     // nalpha = 1 - out[3] = 0: the composite adds (+0 * anything) and leaves out[] as is
     uint8_t* px;
     if (p.layout == VR_LAYOUT_COMPACT) {
         const int k = tile / p.world;
         const int lx = x - tx * p.tile_w, ly = y - ty * p.tile_h;
-        px = p.rgba + ((int64_t)k * p.tile_w * p.tile_h + (int64_t)ly * p.tile_w + lx) * 4;
+        px = fd.rgba + ((int64_t)k * p.tile_w * p.tile_h + (int64_t)ly * p.tile_w + lx) * 4;
     } else {
-        px = p.rgba + (int64_t)y * p.pitch + (int64_t)x * 4;
+        px = fd.rgba + (int64_t)y * p.pitch + (int64_t)x * 4;
     }
     *reinterpret_cast<uint32_t*>(px) =
         quant8(out[0]) | (quant8(out[1]) << 8) | (quant8(out[2]) << 16) | 0xFF000000u;
@@ -797,21 +1171,43 @@ hipError_t launch_fp(const KParams& p, dim3 grid, dim3 block, hipStream_t s) {
     const bool n2 = (p.N == 2) && p.max_depth <= 23;
     const bool lobes = p.format == VR_FORMAT_SG || p.format == VR_FORMAT_ASG;
     if (!n2) return launch_basis<FMA, MODE_GENERIC>(p, grid, block, s);
-    if (lobes || p.counters) return launch_basis<FMA, MODE_FULL>(p, grid, block, s);
+    if (lobes || p.instrumented) return launch_basis<FMA, MODE_FULL>(p, grid, block, s);
     return launch_basis<FMA, MODE_FAST>(p, grid, block, s);
 }
 
 }  // namespace
 
-hipError_t launch_render(const KParams& p, int fp_mode, hipStream_t stream) {
-    if (p.n_wave_blocks <= 0) return hipSuccess;
-    const dim3 block(kWave * kWavesPerBlock);
-    const dim3 grid((unsigned)((p.n_wave_blocks + kWavesPerBlock - 1) / kWavesPerBlock));
+hipError_t launch_render(const KParams& p, const FrameTable& tbl, int fp_mode, int n_waves,
+                         hipStream_t stream) {
+    if (p.n_wave_blocks <= 0 || tbl.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(prepare_launch_kernel, dim3(1), dim3(64), 0, stream, tbl,
+                       const_cast<FrameDesc*>(p.frames), p.queue_head, p.ray_count_rw);
+    const int64_t total_blocks = p.n_wave_blocks * tbl.n;
+    {   // ray generation: kGenWaves wave blocks (8x8 pixels each) per workgroup
+        const dim3 ggrid((unsigned)((total_blocks + kGenWaves - 1) / kGenWaves));
+        const dim3 gblock(kWave * kGenWaves);
+        const bool full = p.instrumented || p.format == VR_FORMAT_SG || p.format == VR_FORMAT_ASG;
+        if (fp_mode == VR_FP_FMA) {
+            if (full) hipLaunchKernelGGL((raygen_kernel<1, true>), ggrid, gblock, 0, stream, p);
+            else hipLaunchKernelGGL((raygen_kernel<1, false>), ggrid, gblock, 0, stream, p);
+        } else {
+            if (full) hipLaunchKernelGGL((raygen_kernel<0, true>), ggrid, gblock, 0, stream, p);
+            else hipLaunchKernelGGL((raygen_kernel<0, false>), ggrid, gblock, 0, stream, p);
+        }
+    }
+    // persistent march grid: enough waves to fill the chip, but no more than one per
+    // ~256 pixels so that small launches still rebalance through the ray queue
+    int64_t want = total_blocks / 4;
+    if (want < 256) want = 256;
+    if (want > n_waves) want = n_waves;
+    if (want > total_blocks) want = total_blocks;
+    const dim3 block(kWave);
+    const dim3 grid((unsigned)want);
     const hipError_t e = fp_mode == VR_FP_FMA ? launch_fp<1>(p, grid, block, stream)
                                               : launch_fp<0>(p, grid, block, stream);
     if (e != hipSuccess || !p.enable_probe || p.probe_disp_size <= 0) return e;
     const int side = p.probe_disp_size + 5;
-    const dim3 pgrid((unsigned)((side * side + 255) / 256));
+    const dim3 pgrid((unsigned)((side * side + 255) / 256), (unsigned)tbl.n);
     if (fp_mode == VR_FP_FMA)
         hipLaunchKernelGGL(probe_overlay_kernel<1>, pgrid, dim3(256), 0, stream, p);
     else
