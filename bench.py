@@ -120,6 +120,7 @@ def main():
     import torch.distributed as dist
 
     from volrend_amd import _abi, api, synth
+    from volrend_amd.dist import GatherPipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -162,68 +163,43 @@ def main():
     # double-buffered outputs: launch j writes set j % 2
     frames = [[torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
               for _ in range(2)]
-    if world > 1:
-        nbytes = api.compact_bytes(W, H, shard)
-        bufs = [torch.zeros((B, nbytes), dtype=torch.uint8, device=dev) for _ in range(2)]
-        gathered = [torch.zeros((world, B, nbytes), dtype=torch.uint8, device=dev)
-                    for _ in range(2)] if rank == 0 else [None, None]
+    nbytes = api.compact_bytes(W, H, shard) if world > 1 else 0
+    pipe = GatherPipeline(
+        dist, rank, world,
+        lambda: torch.zeros((B, max(nbytes, 1)), dtype=torch.uint8, device=dev),
+        lambda: [torch.zeros((B, max(nbytes, 1)), dtype=torch.uint8, device=dev)
+                 for _ in range(world)])
 
     def pose_of(step):
         return transforms[step % len(transforms)]
 
-    def render_launch(j, first_step, n, ev=None):
+    timing = {"events": None}
+
+    def render(j, first_step, n, buf):
         """Launch j renders steps [first_step, first_step+n) in one batch."""
         tr = [pose_of(first_step + i) for i in range(n)]
+        ev = timing["events"][j] if timing["events"] else None
         if ev is not None:
             ev[0].record(stream)
         if world == 1:
             api.launch_renderer_batch(tree, cam, tr, opts, frames[j % 2][:n], stream, True,
                                       fp_mode=fp_mode)
         else:
-            api.launch_renderer_batch(tree, cam, tr, opts, [bufs[j % 2][i] for i in range(n)],
-                                      stream, True, shard=shard, fp_mode=fp_mode)
+            api.launch_renderer_batch(tree, cam, tr, opts, [buf[i] for i in range(n)], stream,
+                                      True, shard=shard, fp_mode=fp_mode)
         if ev is not None:
             ev[1].record(stream)
 
-    works = {}
-
-    def gather_launch(j):
+    def assemble(j, glist, n):
         if world == 1:
-            return
-        if rank == 0:
-            glist = [gathered[j % 2][r] for r in range(world)]
-            works[j] = dist.gather(bufs[j % 2], glist, dst=0, async_op=True)
-        else:
-            works[j] = dist.gather(bufs[j % 2], None, dst=0, async_op=True)
-
-    def retire(j, n):
-        """Launch j's gather must be complete before its buffers are reused."""
-        if world == 1 or j not in works:
-            return
-        works.pop(j).wait()
-        if rank == 0:
-            for i in range(n):
-                # rank-major stack of this frame's compact buffers
-                api.assemble_tiles(frames[j % 2][i], gathered[j % 2][:, i].contiguous(), W, H,
-                                   shard, stream)
+            return  # frames were rendered in place
+        for i in range(n):  # rank-major stack of frame i's compact buffers -> frame
+            api.assemble_tiles(frames[j % 2][i], torch.stack([g[i] for g in glist]), W, H, shard,
+                               stream)
 
     def run(n_steps, first, events=None):
-        sizes = []
-        j = 0
-        done = 0
-        while done < n_steps:
-            n = min(B, n_steps - done)
-            if j >= 2:
-                retire(j - 2, sizes[j - 2])
-            render_launch(j, first + done, n, events[j] if events else None)
-            gather_launch(j)
-            sizes.append(n)
-            done += n
-            j += 1
-        for jj in (j - 2, j - 1):
-            if jj >= 0:
-                retire(jj, sizes[jj])
-        return j
+        timing["events"] = events
+        return pipe.run(n_steps, B, render, assemble, first)
 
     # ---- warm-up (untimed) ---------------------------------------------------
     run(args.warmup, 0)

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/golden_v1.npz -- input trees + expected outputs.
+
+Run in the build container (needs /root/reference for the host build of the
+reference's device code):   python tests/golden/make_golden.py
+
+For every case the file stores the INPUT (tree arrays, pose, intrinsics, options) and
+  rgba_strict / accum_strict : output of the reference's own render_kernel / trace_ray
+                               compiled for the host (oracle/_ref, strict IEEE, det. expf)
+  rgba_fma    / accum_fma    : output of the oracle's FMA-contraction model
+The script refuses to write unless the oracle's strict mode reproduces the reference
+bit for bit on every case.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import binding as ob  # noqa: E402
+from volrend_amd import synth  # noqa: E402
+
+CASES = [
+    dict(name="sh16_default", depth=4, fmt="SH", basis_dim=16, seed=301, pose=2, size=64),
+    dict(name="sh25_fine_steps", depth=4, fmt="SH", basis_dim=25, seed=302, pose=5, size=48,
+         opts=dict(step_size=1e-5, stop_thresh=1e-3)),
+    dict(name="sh9_bbox_bg", depth=5, fmt="SH", basis_dim=9, seed=303, pose=1, size=56,
+         opts=dict(render_bbox=(0.1, 0.15, 0.0, 0.85, 0.9, 0.8), background_brightness=0.3)),
+    dict(name="sh4_ndc", depth=4, fmt="SH", basis_dim=4, seed=304, size=64,
+         transform=[1, 0, 0, 0, 1, 0, 0, 0, 1, 0.05, -0.02, 0.3], ndc=(64.0, 64.0, 55.0),
+         focal=55.0),
+    dict(name="sh1_rot", depth=4, fmt="SH", basis_dim=1, seed=305, pose=6, size=48,
+         opts=dict(rot_dirs=(0.2, -0.4, 0.7))),
+    dict(name="rgba_depth", depth=5, fmt="RGBA", basis_dim=0, seed=306, pose=3, size=48,
+         opts=dict(render_depth=1)),
+    dict(name="rgba_default", depth=5, fmt="RGBA", basis_dim=0, seed=307, pose=7, size=48),
+    dict(name="sg9", depth=4, fmt="SG", basis_dim=9, seed=308, pose=4, size=48),
+    dict(name="asg4", depth=4, fmt="ASG", basis_dim=4, seed=309, pose=0, size=40),
+    dict(name="sh16_ragged_thresh", depth=4, fmt="SH", basis_dim=16, seed=310, pose=2, size=61,
+         height=37, opts=dict(sigma_thresh=20.0, stop_thresh=0.2)),
+]
+
+
+def main():
+    if ob.ref_lib() is None:
+        raise SystemExit("reference host build unavailable: run in the container with /root/reference")
+    out = {}
+    index = []
+    for c in CASES:
+        tree = synth.make_tree(depth=c["depth"], basis_dim=c["basis_dim"], fmt=c["fmt"],
+                               seed=c["seed"])
+        w = c["size"]
+        h = c.get("height", w)
+        focal = c.get("focal", w * 1111.111 / 800.0)
+        if "transform" in c:
+            tr = np.asarray(c["transform"], dtype=np.float32)
+        else:
+            tr = synth.c2w_to_transform(synth.make_poses(8)[c["pose"]])
+        opts = c.get("opts", {})
+        th = ob.TreeHandle(tree, ndc=c.get("ndc"))
+        cam = ob.make_camera(tr, w, h, focal)
+        opt = ob.default_options(**opts)
+        rgba_o, acc_o, cnt = ob.render(th, cam, opt, ob.FP_STRICT)
+        rgba_r = ob.ref_render(th, cam, opt)
+        acc_r = ob.ref_trace(th, cam, opt)
+        if not (np.array_equal(rgba_o, rgba_r) and
+                np.array_equal(acc_o.view(np.uint32), acc_r.view(np.uint32))):
+            raise SystemExit(f"{c['name']}: oracle(strict) != reference host build")
+        rgba_f, acc_f, _ = ob.render(th, cam, opt, ob.FP_FMA)
+        n = c["name"]
+        out[n + "/child"] = tree.child
+        out[n + "/data"] = tree.data.view(np.uint16)
+        if tree.extra is not None:
+            out[n + "/extra"] = tree.extra
+        out[n + "/rgba_strict"] = rgba_r
+        out[n + "/accum_strict"] = acc_r.view(np.uint32)
+        out[n + "/rgba_fma"] = rgba_f
+        out[n + "/accum_fma"] = acc_f.view(np.uint32)
+        index.append(dict(name=n, data_format=tree.data_format, width=w, height=h, focal=focal,
+                          transform=[float(x) for x in tr], ndc=c.get("ndc"), opts=opts,
+                          offset=[float(x) for x in tree.offset],
+                          invradius3=[float(x) for x in tree.invradius3], counters=cnt))
+        print(f"{n}: {tree.capacity} nodes, {cnt['samples']} samples, {cnt['hit_samples']} hits")
+    out["index"] = np.frombuffer(json.dumps(index).encode(), dtype=np.uint8)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_v1.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,134 @@
+"""The C-ABI boundary: include/volrend_hip.h <-> libvolrend_hip.so <-> volrend_amd/_abi.py.
+No GPU needed: only symbol tables, struct layouts and host-only entry points."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from volrend_amd import _abi, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "volrend_hip.h")
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int64_t|int|void|const char\*|char\*)\s*\*?\s*(vr_\w+)\s*\(",
+                       src, flags=re.M)
+    return sorted(set(names))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    if not os.path.exists(_abi.LIB_PATH):
+        build.build()
+    return _abi.LIB_PATH
+
+
+def test_every_header_symbol_is_exported(lib_path):
+    funcs = header_functions()
+    assert len(funcs) >= 18
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib_path], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [f for f in funcs if f not in exported]
+    assert not missing, f"declared in volrend_hip.h but not exported: {missing}"
+    # nothing of the C++ implementation leaks through unmangled
+    stray = [s for s in exported if s.startswith("vr_") and s not in funcs]
+    assert not stray, f"exported but undeclared: {stray}"
+
+
+def test_ctypes_prototypes_cover_the_header(lib_path):
+    assert sorted(_abi.PROTOTYPES) == header_functions()
+    L = _abi.lib()  # resolves every symbol; raises AttributeError otherwise
+    assert L.vr_abi_version() == 1
+
+
+def test_struct_layouts_match_the_c_compiler():
+    structs = {"VrTreeDesc": _abi.VrTreeDesc, "VrTreeInfo": _abi.VrTreeInfo,
+               "VrCamera": _abi.VrCamera, "VrRenderOptions": _abi.VrRenderOptions,
+               "VrFrame": _abi.VrFrame}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "volrend_hip.h"',
+             'int main(void){']
+    for name, st in structs.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for fname, _ in st._fields_:
+            lines.append(f'printf("{name}.{fname} %zu\\n", offsetof({name}, {fname}));')
+    lines.append('printf("VrCounters %zu\\n", sizeof(VrCounters)); return 0;}')
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "layout.c")
+        open(src, "w").write("\n".join(lines))
+        exe = os.path.join(td, "layout")
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        got = dict(l.split() for l in subprocess.check_output([exe], text=True).splitlines())
+    for name, st in structs.items():
+        assert int(got[name]) == C.sizeof(st), name
+        for fname, _ in st._fields_:
+            assert int(got[f"{name}.{fname}"]) == getattr(st, fname).offset, f"{name}.{fname}"
+    assert int(got["VrCounters"]) == 8 * len(_abi.COUNTER_FIELDS)
+
+
+def test_host_only_entry_points(lib_path):
+    L = _abi.lib()
+    o = _abi.VrRenderOptions()
+    L.vr_default_options(C.byref(o))
+    # render_options.hpp:11-53 defaults
+    assert abs(o.step_size - 1e-4) < 1e-10 and abs(o.sigma_thresh - 1e-2) < 1e-9
+    assert abs(o.stop_thresh - 1e-2) < 1e-9 and o.background_brightness == 1.0
+    assert list(o.render_bbox) == [0, 0, 0, 1, 1, 1] and list(o.basis_minmax) == [0, 24]
+    assert o.probe_disp_size == 100 and o.grid_max_depth == 4 and list(o.probe) == [0, 0, 1]
+    f = _abi.VrFrame()
+    L.vr_default_frame(C.byref(f))
+    assert f.offscreen == 1 and f.world == 1 and f.layout == _abi.LAYOUT_FRAME
+    # compact buffer size of the 8-row-band shard used by bench.py at 8 GPUs
+    assert L.vr_compact_bytes(800, 800, 800, 8, 8) == 13 * 800 * 8 * 4
+    assert L.vr_compact_bytes(800, 800, 0, 0, 1) == 800 * 800 * 4
+    assert L.vr_compact_bytes(800, 800, 12, 8, 2) == -1  # not a multiple of 8
+    assert b"multiples of 8" in L.vr_last_error()
+    assert L.vr_set_tuning(b"no_such_knob", 1) != 0
+    assert L.vr_set_tuning(b"march_max", 2) == 0
+    # argument validation happens before any device call
+    assert L.vr_tree_upload(None, None) == 1
+    d = _abi.VrTreeDesc()
+    L.vr_default_tree_desc(C.byref(d))
+    h = C.c_void_p()
+    assert L.vr_tree_upload(C.byref(d), C.byref(h)) == 1 and not h.value
+
+
+def test_bad_trees_are_rejected_on_the_host(lib_path):
+    """Topology validation runs before any device work: cycles / out-of-range links
+    would otherwise hang the descent loop on the GPU."""
+    import numpy as np
+    L = _abi.lib()
+
+    def try_upload(child):
+        child = np.ascontiguousarray(child, dtype=np.int32)
+        cap = child.shape[0]
+        data = np.zeros((cap, 8, 4), dtype=np.float16)
+        d = _abi.VrTreeDesc()
+        L.vr_default_tree_desc(C.byref(d))
+        d.child, d.data = child.ctypes.data, data.ctypes.data
+        d.capacity, d.data_dim, d.N = cap, 4, 2
+        for i in range(3):
+            d.scale[i], d.offset[i] = 1.0, 0.0
+        h = C.c_void_p()
+        rc = L.vr_tree_upload(C.byref(d), C.byref(h))
+        return rc, L.vr_last_error().decode()
+
+    cyc = np.zeros((2, 8), np.int32)
+    cyc[0, 0] = 1
+    cyc[1, 0] = -1  # child points back at the root
+    rc, msg = try_upload(cyc)
+    assert rc == 4 and "bad tree" in msg
+    oob = np.zeros((2, 8), np.int32)
+    oob[0, 3] = 5
+    rc, msg = try_upload(oob)
+    assert rc == 4 and "outside" in msg
+    dag = np.zeros((3, 8), np.int32)
+    dag[0, 0] = 1
+    dag[0, 1] = 1  # two slots share one child
+    rc, msg = try_upload(dag)
+    assert rc == 4

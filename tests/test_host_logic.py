@@ -1,0 +1,145 @@
+"""Host-side logic: synthetic assets, the tree.npz format, DataFormat parsing, the
+quantised-codebook decode, pose files, tile sharding math."""
+import os
+
+import numpy as np
+import pytest
+
+from volrend_amd import api, synth, tiles
+
+
+def test_data_format_parse():
+    # DataFormat::parse, src/n3tree.cpp:55-78
+    assert api.parse_data_format("SH16") == ("SH", 16)
+    assert api.parse_data_format("SG25") == ("SG", 25)
+    assert api.parse_data_format("ASG4") == ("ASG", 4)
+    assert api.parse_data_format("RGBA") == ("RGBA", -1)
+    assert api.parse_data_format("XYZ9")[0] == "RGBA"
+
+
+def test_tree_topology_invariants():
+    t = synth.make_tree(depth=5, basis_dim=4, seed=1)
+    child = t.child.reshape(t.capacity, 8)
+    n = np.arange(t.capacity)[:, None]
+    tgt = np.where(child != 0, n + child, -1)
+    linked = tgt[tgt >= 0]
+    assert (linked > 0).all() and (linked < t.capacity).all()
+    assert len(np.unique(linked)) == len(linked) == t.capacity - 1  # every non-root node once
+    # breadth-first numbering: children come after their parent
+    assert (child >= 0).all()
+    # occupied leaves only at the finest level, all other records are zero
+    sig = t.data.reshape(t.capacity, 8, -1)[..., -1]
+    assert (sig[child != 0] == 0).all()
+    assert (sig > 0).sum() == t.meta["shell_leaves"] > 0
+
+
+def test_npz_round_trip(tmp_path):
+    t = synth.make_tree(depth=4, basis_dim=9, seed=2)
+    for compressed in (False, True):
+        p = str(tmp_path / f"tree_{int(compressed)}.npz")
+        synth.save_npz(t, p, compressed=compressed)
+        z = np.load(p)
+        # key layout read by N3Tree::load_npz (src/n3tree.cpp:228-277)
+        assert z["data_dim"].dtype == np.int64 and z["data_dim"].shape == ()
+        assert z["data_format"].dtype.kind == "U" and str(z["data_format"]) == "SH9"
+        assert z["child"].dtype == np.int32 and z["child"].shape == (t.capacity, 2, 2, 2)
+        assert z["data"].dtype == np.float16 and z["data"].shape[-1] == 28
+        assert z["invradius3"].dtype == np.float32 and z["offset"].dtype == np.float32
+        n = api.N3Tree()
+        n.open(p, upload=False)
+        assert n.N == 2 and n.capacity == t.capacity and n.data_dim == 28
+        assert n.data_format == ("SH", 9)
+        assert np.array_equal(n.child_, t.child) and np.array_equal(n.data_, t.data)
+        assert np.allclose(n.scale, t.invradius3) and np.allclose(n.offset, t.offset)
+        assert not n.use_ndc
+
+
+def test_legacy_npz_without_format_and_ndc_sidecar(tmp_path):
+    t = synth.make_tree(depth=3, basis_dim=4, seed=3)
+    p = str(tmp_path / "old.npz")
+    np.savez(p, data_dim=np.int64(t.data_dim), child=t.child, data=t.data,
+             invradius=np.float64(0.25), offset=t.offset)
+    pb = np.zeros((3, 17))
+    pb[:, 4], pb[:, 9], pb[:, 14] = 378.0, 504.0, 410.0  # H, W, focal (n3tree.cpp:26-28)
+    np.save(str(tmp_path / "old_poses_bounds.npy"), pb)
+    n = api.N3Tree()
+    n.open(p, upload=False)
+    assert n.data_format == ("SH", 4)          # autodetect, n3tree.cpp:247-253
+    assert np.allclose(n.scale, 0.25)          # scalar invradius, n3tree.cpp:260-262
+    assert n.use_ndc and (n.ndc_width, n.ndc_height, n.ndc_focal) == (504.0, 378.0, 410.0)
+    with pytest.raises(RuntimeError):
+        api.N3Tree.from_arrays(t.child, t.data.astype(np.float32), t.offset, t.invradius3, "SH4",
+                               upload=False)  # "data must be stored in half precision"
+
+
+def test_quantised_tree_decodes_to_the_same_data(tmp_path):
+    """compress_octree.py layout (scripts/compress_octree.py:106-119) with --retain 1:
+    decode per src/n3tree.cpp:279-340 must reproduce the data array."""
+    t = synth.make_tree(depth=3, basis_dim=4, seed=4)
+    cap, dd, nb = t.capacity, t.data_dim, 4
+    data = t.data.reshape(-1, dd)
+    n_slots = data.shape[0]
+    coeff = data[:, :-1].reshape(n_slots, 3, nb)           # [slot, channel, basis]
+    retained = coeff[:, :, 0][None]                         # [1, slot, 3]
+    quant_colors = np.zeros((nb - 1, 65536, 3), np.float16)
+    quant_map = np.zeros((nb - 1, n_slots), np.uint16)
+    for j in range(1, nb):
+        cols = coeff[:, :, j]                               # [slot, 3]
+        uniq, inv = np.unique(cols, axis=0, return_inverse=True)
+        assert len(uniq) <= 65536
+        quant_colors[j - 1, :len(uniq)] = uniq
+        quant_map[j - 1] = inv.reshape(-1).astype(np.uint16)
+    p = str(tmp_path / "q.npz")
+    np.savez_compressed(p, data_dim=np.int64(dd), data_format=np.array("SH4"), child=t.child,
+                        invradius3=t.invradius3, offset=t.offset, quant_colors=quant_colors,
+                        quant_map=quant_map.reshape(nb - 1, cap, 2, 2, 2),
+                        sigma=data[:, -1].reshape(cap, 2, 2, 2),
+                        data_retained=retained.reshape(1, cap, 2, 2, 2, 3))
+    n = api.N3Tree()
+    n.open(p, upload=False)
+    assert np.array_equal(n.data_.view(np.uint16), t.data.view(np.uint16))
+
+
+def test_pose_files_round_trip(tmp_path):
+    poses = synth.make_poses(4)
+    paths = synth.write_pose_dir(str(tmp_path), poses, 800, 1111.111)
+    assert [os.path.basename(p) for p in paths] == ["0000.txt", "0001.txt", "0002.txt", "0003.txt"]
+    m = np.loadtxt(paths[2])
+    assert m.shape == (4, 4) and np.allclose(m, poses[2])
+    K = np.loadtxt(str(tmp_path / "intrinsics.txt"))
+    assert K[0, 0] == pytest.approx(1111.111) and K[1, 1] == pytest.approx(1111.111)
+    tr = synth.c2w_to_transform(m)
+    # column-major 4x3: right, up, back, centre (main_headless.cpp:51-56)
+    assert np.allclose(tr[9:12], m[:3, 3]) and np.allclose(tr[0:3], m[:3, 0])
+    cam = api.Camera(800, 800, 1111.111)
+    cam.set_c2w(m)
+    assert np.array_equal(cam.transform, tr)
+    # camera looks down -z of the c2w and sits on the r=4 orbit
+    assert np.linalg.norm(m[:3, 3]) == pytest.approx(4.0)
+
+
+def test_render_options_defaults_match_reference():
+    o = api.RenderOptions()
+    c = o.to_c()
+    assert (c.step_size, c.sigma_thresh, c.stop_thresh) == pytest.approx((1e-4, 1e-2, 1e-2))
+    assert list(c.basis_minmax) == [0, 24] and list(c.render_bbox) == [0, 0, 0, 1, 1, 1]
+    assert c.render_depth == 0 and c.enable_probe == 0 and c.probe_disp_size == 100
+
+
+@pytest.mark.parametrize("w,h,tw,th,world", [(800, 800, 800, 8, 8), (100, 61, 32, 16, 3),
+                                             (64, 64, 8, 8, 4), (1920, 1080, 1920, 8, 8),
+                                             (50, 50, 0, 0, 1)])
+def test_tile_shard_round_trip(w, h, tw, th, world):
+    rng = np.random.default_rng(w + h)
+    frame = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    parts = [tiles.frame_to_compact(frame, tw, th, r, world) for r in range(world)]
+    n = tiles.compact_pixels(w, h, tw, th, world)
+    assert all(p.shape == (n, 4) for p in parts)
+    back = tiles.assemble_tiles(np.stack(parts), w, h, tw, th, world)
+    assert np.array_equal(back, frame)
+    own = tiles.owner_map(w, h, tw, th, world)
+    counts = np.bincount(own.reshape(-1), minlength=world)
+    assert counts.sum() == w * h and (counts > 0).all()
+    # agrees with the C ABI's buffer size
+    from volrend_amd import _abi
+    assert _abi.lib().vr_compact_bytes(w, h, tw, th, world) == n * 4

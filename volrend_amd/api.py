@@ -117,7 +117,7 @@ def parse_data_format(s: str):
 class N3Tree:
     """Read-only N^3 tree: host arrays + the device copy behind an opaque handle."""
 
-    def __init__(self, path: str | None = None):
+    def __init__(self, path: str | None = None, upload: bool = True):
         self.N = 0
         self.data_dim = 0
         self.data_format = ("RGBA", -1)
@@ -132,7 +132,7 @@ class N3Tree:
         self._handle = C.c_void_p()
         self._loaded = False
         if path is not None:
-            self.open(path)
+            self.open(path, upload=upload)
 
     # ---- construction ----------------------------------------------------
     @classmethod
@@ -167,8 +167,9 @@ class N3Tree:
         self.offset = np.asarray(offset, dtype=np.float32).reshape(3).copy()
         self.extra_ = None if extra is None else np.ascontiguousarray(extra, dtype=np.float32)
 
-    def open(self, path: str) -> None:
-        """``N3Tree::open`` + ``load_npz`` (src/n3tree.cpp:111-154, 228-362)."""
+    def open(self, path: str, upload: bool = True) -> None:
+        """``N3Tree::open`` + ``load_npz`` (src/n3tree.cpp:111-154, 228-362).
+        ``upload=False`` stops before ``load_cuda`` (host-only use, e.g. format tests)."""
         if not path.endswith(".npz"):
             raise ValueError("tree file must end in .npz")  # assert at n3tree.cpp:119
         if not os.path.exists(path):
@@ -199,7 +200,8 @@ class N3Tree:
             self.use_ndc = True
             self.ndc_height, self.ndc_width, self.ndc_focal = float(arr[4]), float(arr[9]), float(
                 arr[14])
-        self.load_device()
+        if upload:
+            self.load_device()
 
     # ---- device ----------------------------------------------------------
     def load_device(self) -> None:
@@ -403,7 +405,7 @@ def set_tuning(**kw) -> None:
 def compact_bytes(width: int, height: int, shard: TileShard) -> int:
     n = _abi.lib().vr_compact_bytes(width, height, shard.tile_w, shard.tile_h, shard.world)
     if n < 0:
-        _abi.check(1)
+        raise _abi.VolrendError(1, (_abi.lib().vr_last_error() or b"").decode())
     return int(n)
 
 

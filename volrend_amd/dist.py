@@ -1,0 +1,60 @@
+"""Multi-GPU frame pipeline: screen-tile shard + gather of the RGBA8 tiles to rank 0.
+
+One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI on the GPU
+box, "gloo" in the CPU tests).  The tree is replicated; every launch renders this rank's
+interleaved tiles of ``n`` frames into a COMPACT buffer (``VrFrame.layout``), ONE gather
+per launch moves the buffers to rank 0 -- each peer sends its ~1/world share straight to
+the root over its direct xGMI link -- and rank 0 de-interleaves them into frames.
+The gather of launch j overlaps the rendering of launch j+1 (two buffer sets).
+
+The rendering and the assembly are callbacks, so the same pipeline drives the HIP
+library on GPUs and the CPU oracle in the gloo tests.
+"""
+from __future__ import annotations
+
+
+class GatherPipeline:
+    def __init__(self, dist, rank: int, world: int, make_buffer, make_gather_list):
+        """``make_buffer()`` -> this rank's compact buffer (tensor) for one launch;
+        ``make_gather_list()`` -> list of ``world`` tensors like it (rank 0 only)."""
+        self.dist, self.rank, self.world = dist, rank, world
+        self.bufs = [make_buffer() for _ in range(2)]
+        self.gathered = [make_gather_list() if rank == 0 else None for _ in range(2)]
+        self.works = {}
+        self.sizes = {}
+
+    def buffer(self, j: int):
+        return self.bufs[j % 2]
+
+    def submit(self, j: int, n: int) -> None:
+        """Launch j has been enqueued into buffer(j): start its gather."""
+        self.sizes[j] = n
+        if self.world == 1:
+            return
+        self.works[j] = self.dist.gather(self.bufs[j % 2], self.gathered[j % 2], dst=0,
+                                         async_op=True)
+
+    def retire(self, j: int, assemble) -> None:
+        """Wait for launch j's gather; rank 0 calls ``assemble(j, gathered_list, n)``.
+        Must be called before buffer(j + 2) is written."""
+        if j not in self.sizes:
+            return
+        n = self.sizes.pop(j)
+        if self.world > 1:
+            self.works.pop(j).wait()
+        if self.rank == 0:
+            assemble(j, self.gathered[j % 2] if self.world > 1 else [self.bufs[j % 2]], n)
+
+    def run(self, n_steps: int, batch: int, render, assemble, first_step: int = 0) -> int:
+        """render(j, first_step, n, buffer) enqueues one launch; returns launches done."""
+        j, done = 0, 0
+        while done < n_steps:
+            n = min(batch, n_steps - done)
+            self.retire(j - 2, assemble)
+            render(j, first_step + done, n, self.buffer(j))
+            self.submit(j, n)
+            done += n
+            j += 1
+        self.retire(j - 2, assemble)
+        self.retire(j - 1, assemble)
+        return j
