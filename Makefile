@@ -1,0 +1,42 @@
+# Builds everything native in-tree:
+#   make lib      -> volrend_amd/libvolrend_hip.so   (gfx950 kernels + C ABI, hipcc)
+#   make host     -> volrend_amd/libvolrend_host.a   (kept C++ host layer, g++)
+#   make cli      -> volrend_amd/bin/volrend_headless
+#   make oracle   -> oracle/liboracle.so (+ oracle/_ref when /root/reference is mounted)
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+ROCM ?= /opt/rocm
+PKG = volrend_amd
+HOST = $(PKG)/csrc/host
+HOST_SRC = $(HOST)/npz.cpp $(HOST)/n3tree.cpp $(HOST)/camera.cpp $(HOST)/opts.cpp \
+           $(HOST)/imwrite.cpp $(HOST)/renderer.cpp
+HOST_OBJ = $(HOST_SRC:.cpp=.o)
+CXXFLAGS = -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude
+
+all: lib host cli
+
+lib:
+	python3 -m volrend_amd.build
+
+$(HOST)/%.o: $(HOST)/%.cpp
+	$(CXX) $(CXXFLAGS) -c $< -o $@
+
+host: $(PKG)/libvolrend_host.a
+$(PKG)/libvolrend_host.a: $(HOST_OBJ)
+	ar rcs $@ $(HOST_OBJ)
+
+cli: $(PKG)/bin/volrend_headless
+$(PKG)/bin/volrend_headless: $(HOST)/main_headless.cpp $(PKG)/libvolrend_host.a lib
+	mkdir -p $(PKG)/bin
+	$(CXX) -O2 -std=c++17 -Iinclude -I$(ROCM)/include -D__HIP_PLATFORM_AMD__ \
+	  $(HOST)/main_headless.cpp $(PKG)/libvolrend_host.a -L$(PKG) -lvolrend_hip \
+	  -L$(ROCM)/lib -lamdhip64 -lz -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,$(ROCM)/lib -o $@
+
+oracle:
+	$(MAKE) -C oracle
+	if [ -d /root/reference ]; then $(MAKE) -C oracle ref; fi
+
+clean:
+	rm -f $(HOST_OBJ) $(PKG)/libvolrend_host.a $(PKG)/bin/volrend_headless
+
+.PHONY: all lib host cli oracle clean

@@ -1,0 +1,42 @@
+// Minimal .npy / .npz reader for the tree files (stored + deflate members, ZIP64, '<U'
+// strings, in-memory archives).  Written for this repo; plays the role cnpy plays in the
+// reference (3rdparty/cnpy) without sharing code with it.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace volrend {
+namespace internal {
+
+struct NpyArray {
+    std::vector<uint8_t> data_holder;
+    std::vector<size_t> shape;
+    size_t word_size = 0;
+    char kind = 0;  // numpy dtype kind: 'f', 'i', 'u', 'U', 'b', ...
+    bool fortran_order = false;
+    size_t num_vals = 0;
+
+    template <typename T>
+    T* data() { return reinterpret_cast<T*>(data_holder.data()); }
+    template <typename T>
+    const T* data() const { return reinterpret_cast<const T*>(data_holder.data()); }
+    size_t num_bytes() const { return data_holder.size(); }
+    bool empty() const { return data_holder.empty(); }
+    // scalar / first element as double (any numeric dtype)
+    double as_double(size_t i = 0) const;
+    // '<U..' or '|S..' array as an ASCII string
+    std::string as_string() const;
+};
+
+using NpzFile = std::map<std::string, NpyArray>;
+
+NpyArray npy_load(const std::string& path);
+NpyArray npy_parse(const uint8_t* bytes, size_t size);
+NpzFile npz_load(const std::string& path);
+NpzFile npz_load_mem(const uint8_t* bytes, size_t size);
+
+}  // namespace internal
+}  // namespace volrend

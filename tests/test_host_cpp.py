@@ -1,0 +1,148 @@
+"""The kept C++ host layer (include/volrend/*.hpp, volrend_amd/csrc/host): npz reader,
+N3Tree loader (plain / deflated / legacy / quantised / NDC sidecar), option parser, PNG
+writer.  No device: N3Tree::upload_on_open is cleared by the helper."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from volrend_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def fnv(b: bytes) -> int:
+    h = 1469598103934665603
+    for byte in np.frombuffer(b, dtype=np.uint8).tolist():
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def fnv_np(a: np.ndarray) -> int:
+    # vectorised FNV is awkward; arrays in these tests are small
+    return fnv(np.ascontiguousarray(a).tobytes())
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    subprocess.check_call(["make", "-C", ROOT, "host"], stdout=subprocess.DEVNULL)
+    out = str(tmp_path_factory.mktemp("bin") / "host_check")
+    # the loader references vr_tree_upload & co: link the real library (never called here)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "host_check.cpp"),
+                           os.path.join(ROOT, "volrend_amd", "libvolrend_host.a"),
+                           "-L", os.path.join(ROOT, "volrend_amd"), "-lvolrend_hip", "-lz",
+                           "-Wl,-rpath," + os.path.join(ROOT, "volrend_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+    return out
+
+
+def run(exe, *args):
+    out = subprocess.check_output([exe, *args], text=True, stderr=subprocess.DEVNULL)
+    return "\n".join(l for l in out.splitlines() if not l.startswith("INFO:"))
+
+
+def parse_kv(line):
+    return dict(tok.split("=", 1) for tok in line.split())
+
+
+@pytest.mark.parametrize("compressed", [False, True])
+def test_npz_members(exe, tmp_path, compressed):
+    t = synth.make_tree(depth=3, basis_dim=4, seed=21)
+    p = str(tmp_path / "t.npz")
+    synth.save_npz(t, p, compressed=compressed)
+    z = np.load(p)
+    lines = {l.split()[0]: l for l in run(exe, "npz", p).splitlines()}
+    assert set(lines) == set(z.files)
+    for k in z.files:
+        a = z[k]
+        kv = parse_kv(lines[k].split(" ", 1)[1])
+        assert kv["kind"] == a.dtype.kind
+        assert int(kv["word"]) == a.dtype.itemsize
+        assert [int(x) for x in kv["shape"].split(",") if x] == list(a.shape)
+        assert int(kv["fnv"]) == fnv_np(a)
+
+
+def test_tree_loader_plain_and_legacy_and_ndc(exe, tmp_path):
+    t = synth.make_tree(depth=3, basis_dim=9, seed=22)
+    p = str(tmp_path / "a.npz")
+    synth.save_npz(t, p, compressed=True)
+    out = run(exe, "tree", p).splitlines()
+    facts = parse_kv(out[0])
+    assert facts == dict(N="2", capacity=str(t.capacity), data_dim="28", format="SH9", loaded="1")
+    assert "ndc=0" in out[2]
+    kv = parse_kv(out[3])
+    assert int(kv["child_fnv"]) == fnv_np(t.child) and int(kv["data_fnv"]) == fnv_np(t.data)
+    assert out[4] == "pack=3,1,0,1"
+    # legacy keys + LLFF sidecar
+    q = str(tmp_path / "old.npz")
+    np.savez(q, data_dim=np.int64(t.data_dim), child=t.child, data=t.data,
+             invradius=np.float64(0.25), offset=t.offset)
+    pb = np.zeros((3, 17))
+    pb[:, 4], pb[:, 9], pb[:, 14] = 378.0, 504.0, 410.0
+    pb[:, 15], pb[:, 16] = 1.0, 9.0
+    pb[:, 0:15:5] = 0.1
+    np.save(str(tmp_path / "old_poses_bounds.npy"), pb)
+    out = run(exe, "tree", q).splitlines()
+    assert parse_kv(out[0])["format"] == "SH9"
+    assert out[1].startswith("scale=0.25,0.25,0.25")
+    assert out[2].split()[0:4] == ["ndc=1", "504", "378", "410"]
+
+
+def test_tree_loader_quantised(exe, tmp_path):
+    t = synth.make_tree(depth=3, basis_dim=4, seed=23)
+    cap, dd, nb = t.capacity, t.data_dim, 4
+    data = t.data.reshape(-1, dd)
+    n_slots = data.shape[0]
+    coeff = data[:, :-1].reshape(n_slots, 3, nb)
+    retained = coeff[:, :, 0][None]
+    qc = np.zeros((nb - 1, 65536, 3), np.float16)
+    qm = np.zeros((nb - 1, n_slots), np.uint16)
+    for j in range(1, nb):
+        uniq, inv = np.unique(coeff[:, :, j], axis=0, return_inverse=True)
+        qc[j - 1, :len(uniq)] = uniq
+        qm[j - 1] = inv.reshape(-1).astype(np.uint16)
+    p = str(tmp_path / "q.npz")
+    np.savez_compressed(p, data_dim=np.int64(dd), data_format=np.array("SH4"), child=t.child,
+                        invradius3=t.invradius3, offset=t.offset, quant_colors=qc,
+                        quant_map=qm.reshape(nb - 1, cap, 2, 2, 2),
+                        sigma=data[:, -1].reshape(cap, 2, 2, 2),
+                        data_retained=retained.reshape(1, cap, 2, 2, 2, 3))
+    out = run(exe, "tree", p).splitlines()
+    assert int(parse_kv(out[3])["data_fnv"]) == fnv_np(t.data)
+
+
+def test_loader_errors(exe, tmp_path):
+    t = synth.make_tree(depth=2, basis_dim=1, seed=24)
+    p = str(tmp_path / "f32.npz")
+    np.savez(p, data_dim=np.int64(t.data_dim), data_format=np.array("SH1"), child=t.child,
+             data=t.data.astype(np.float32), invradius3=t.invradius3, offset=t.offset)
+    r = subprocess.run([exe, "tree", p], capture_output=True, text=True)
+    assert r.returncode == 3 and "half precision" in r.stdout
+    r = subprocess.run([exe, "tree", str(tmp_path / "nope.npz")], capture_output=True, text=True)
+    assert "does not exist" in r.stdout and "loaded=0" in r.stdout
+
+
+def test_png_writer(exe, tmp_path):
+    from PIL import Image
+    p = str(tmp_path / "g.png")
+    run(exe, "png", p, "37", "21")
+    im = np.asarray(Image.open(p))
+    assert im.shape == (21, 37, 4)
+    ys, xs = np.mgrid[0:21, 0:37]
+    assert np.array_equal(im[..., 0], (xs * 3) % 256) and np.array_equal(im[..., 1], (ys * 5) % 256)
+    assert np.array_equal(im[..., 2], (xs ^ ys) % 256) and (im[..., 3] == 255).all()
+
+
+def test_option_parser(exe):
+    out = run(exe, "opts", "tree.npz", "pose/0000.txt", "-w", "400", "--height=300", "--fx", "555.5",
+              "-o", "out", "-r", "-s", "1e-3", "--bg", "0.5", "pose/0001.txt", "--unknown", "-e",
+              "0.05").splitlines()
+    kv = parse_kv(out[0])
+    assert kv["file"] == "tree.npz" and kv["w"] == "400" and kv["h"] == "300"
+    assert float(kv["fx"]) == pytest.approx(555.5) and float(kv["bg"]) == 0.5
+    assert float(kv["step"]) == pytest.approx(1e-3) and float(kv["stop"]) == pytest.approx(0.05)
+    assert float(kv["sigma"]) == pytest.approx(1e-2) and kv["out"] == "out" and kv["r"] == "1"
+    assert kv["gpu"] == "-1"
+    assert out[1:] == ["unmatched=pose/0000.txt", "unmatched=pose/0001.txt", "unmatched=--unknown"]

@@ -1,0 +1,251 @@
+// volrend_headless -- offscreen PlenOctree rendering on MI355X.
+// Same command line, pose / intrinsics file formats, PNG naming and the two result lines
+// ("%.10f ms per frame", "%.10f fps") as the reference's main_headless.cpp; the device
+// work goes through the C ABI (include/volrend_hip.h).  Poses are known up front, so they
+// are rendered in batches of --batch frames per launch (default 16).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include <sys/stat.h>
+
+#include "volrend/internal/imwrite.hpp"
+#include "volrend/internal/opts.hpp"
+#include "volrend/n3tree.hpp"
+#include "volrend/renderer_kernel.hpp"
+
+namespace {
+
+#define HIP_OK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, \
+                    __LINE__);                                                         \
+            std::exit(1);                                                              \
+        }                                                                              \
+    } while (0)
+
+std::string path_basename(const std::string& str) {
+    const size_t p = str.find_last_of("/\\");
+    return p == std::string::npos ? str : str.substr(p + 1);
+}
+
+std::string remove_ext(const std::string& str) {
+    const size_t p = str.find_last_of('.');
+    return p == std::string::npos ? str : str.substr(0, p);
+}
+
+// A pose file holds one or more row-major 3x4 / 4x4 matrices (main_headless.cpp:40-63);
+// each becomes a column-major 4x3 (right, up, back, centre).
+int read_transform_matrices(const std::string& path, std::vector<glm::mat4x3>& out) {
+    std::ifstream ifs(path);
+    if (!ifs) {
+        fprintf(stderr, "ERROR: '%s' does not exist\n", path.c_str());
+        std::exit(1);
+    }
+    int cnt = 0;
+    while (ifs) {
+        glm::mat4x3 m;
+        float garb;
+        ifs >> m[0][0] >> m[1][0] >> m[2][0] >> m[3][0];
+        if (!ifs) break;
+        ifs >> m[0][1] >> m[1][1] >> m[2][1] >> m[3][1];
+        ifs >> m[0][2] >> m[1][2] >> m[2][2] >> m[3][2];
+        if (ifs) ifs >> garb >> garb >> garb >> garb;  // optional 4th row
+        ++cnt;
+        out.push_back(m);
+    }
+    return cnt;
+}
+
+void read_intrins(const std::string& path, float& fx, float& fy) {
+    std::ifstream ifs(path);
+    if (!ifs) {
+        fprintf(stderr, "ERROR: intrin '%s' does not exist\n", path.c_str());
+        std::exit(1);
+    }
+    float g;
+    ifs >> fx >> g >> g >> g;
+    ifs >> g >> fy;
+}
+
+void make_dirs(const std::string& path) {
+    std::string cur;
+    for (size_t i = 0; i <= path.size(); ++i) {
+        if (i == path.size() || path[i] == '/') {
+            if (!cur.empty()) mkdir(cur.c_str(), 0755);
+        }
+        if (i < path.size()) cur.push_back(path[i]);
+    }
+}
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+    using namespace volrend;
+    internal::Options args("volrend_headless",
+                           "Headless PlenOctree volume rendering on MI355X (HIP)");
+    internal::add_common_opts(args);
+    args.add("write_images", 'o', false, "",
+             "output directory of images; if empty, DOES NOT save (for timing only)");
+    args.add("intrin", 'i', false, "", "intrinsics matrix 4x4; if set, overrides the fx/fy");
+    args.add("reverse_yz", 'r', true, "", "use OpenCV camera space convention instead of NeRF");
+    args.add("scale", 0, false, "1.0", "scaling to apply to image");
+    args.add("max_imgs", 0, false, "0", "max images to render, default no limit");
+    args.add("batch", 0, false, "16", "poses per launch (1..16)");
+    args.add("fp", 0, false, "strict", "floating-point model: strict | fma");
+    try {
+        internal::parse_options(args, argc, argv);
+    } catch (const std::exception& e) {
+        fprintf(stderr, "ERROR: %s\n", e.what());
+        return 1;
+    }
+
+    const int device_id = args.as_int("gpu");
+    if (device_id >= 0 && vr_set_device(device_id) != VR_OK) {
+        fprintf(stderr, "ERROR: %s\n", vr_last_error());
+        return 1;
+    }
+
+    // Load all transform matrices
+    std::vector<glm::mat4x3> trans;
+    std::vector<std::string> basenames;
+    for (const std::string& path : args.unmatched()) {
+        if (!path.empty() && path[0] == '-') continue;  // an unknown option, not a pose file
+        const int cnt = read_transform_matrices(path, trans);
+        const std::string fname = remove_ext(path_basename(path));
+        if (cnt == 1) {
+            basenames.push_back(fname);
+        } else {
+            for (int i = 0; i < cnt; ++i) {
+                std::string tmp = std::to_string(i);
+                while (tmp.size() < 6) tmp = "0" + tmp;
+                basenames.push_back(fname + "_" + tmp);
+            }
+        }
+    }
+    if (args.as_bool("reverse_yz")) {
+        puts("INFO: Use OpenCV camera convention\n");
+        for (auto& t : trans) {  // c2w * diag(1, -1, -1, 1): flip the up and back columns
+            t[1] = t[1] * -1.f;
+            t[2] = t[2] * -1.f;
+        }
+    } else {
+        puts("INFO: Use NeRF camera convention\n");
+    }
+    if (trans.empty()) {
+        fputs("WARNING: No camera poses specified, quitting\n", stderr);
+        return 1;
+    }
+    const std::string out_dir = args.str("write_images");
+
+    N3Tree tree;
+    try {
+        tree.open(args.str("file"));
+    } catch (const std::exception& e) {
+        fprintf(stderr, "ERROR: %s\n", e.what());
+        return 1;
+    }
+    if (!tree.is_cuda_loaded()) return 1;
+
+    int width = args.as_int("width"), height = args.as_int("height");
+    float fx = args.as_float("fx");
+    if (fx < 0) fx = 1111.11f;
+    float fy = args.as_float("fy");
+    if (fy < 0) fy = fx;
+    if (!args.str("intrin").empty()) read_intrins(args.str("intrin"), fx, fy);
+    {
+        const float scale = args.as_float("scale");
+        if (scale != 1.f) {
+            const int owidth = width, oheight = height;
+            width = (int)(width * scale);
+            height = (int)(height * scale);
+            fx *= (float)width / owidth;
+            fy *= (float)height / oheight;
+        }
+    }
+    {
+        const int max_imgs = args.as_int("max_imgs");
+        if (max_imgs > 0 && trans.size() > (size_t)max_imgs) {
+            trans.resize(max_imgs);
+            basenames.resize(max_imgs);
+        }
+    }
+    int batch = args.as_int("batch");
+    if (batch < 1) batch = 1;
+    if (batch > VR_MAX_BATCH) batch = VR_MAX_BATCH;
+    const int fp_mode = args.str("fp") == "fma" ? VR_FP_FMA : VR_FP_STRICT;
+
+    const size_t frame_bytes = (size_t)width * height * 4;
+    std::vector<void*> images(batch);
+    for (int i = 0; i < batch; ++i) HIP_OK(hipMalloc(&images[i], frame_bytes));
+    std::vector<uint8_t> buf;
+    if (!out_dir.empty()) {
+        make_dirs(out_dir);
+        buf.resize(frame_bytes);
+    }
+    hipStream_t stream;
+    HIP_OK(hipStreamCreate(&stream));
+    hipEvent_t start, stop;
+    HIP_OK(hipEventCreate(&start));
+    HIP_OK(hipEventCreate(&stop));
+    const RenderOptions options = internal::render_options_from_args(args);
+    VrRenderOptions copt;
+    vr_default_options(&copt);
+    copt.step_size = options.step_size;
+    copt.sigma_thresh = options.sigma_thresh;
+    copt.stop_thresh = options.stop_thresh;
+    copt.background_brightness = options.background_brightness;
+
+    HIP_OK(hipEventRecord(start, stream));
+    for (size_t first = 0; first < trans.size(); first += batch) {
+        const int n = (int)std::min<size_t>(batch, trans.size() - first);
+        VrCamera cams[VR_MAX_BATCH];
+        VrFrame frames[VR_MAX_BATCH];
+        for (int i = 0; i < n; ++i) {
+            const float* m = glm::value_ptr(trans[first + i]);
+            for (int k = 0; k < 12; ++k) cams[i].transform[k] = m[k];
+            cams[i].width = width;
+            cams[i].height = height;
+            cams[i].fx = fx;
+            cams[i].fy = fy;
+            vr_default_frame(&frames[i]);
+            frames[i].rgba = images[i];
+            frames[i].offscreen = 1;
+            frames[i].fp_mode = fp_mode;
+        }
+        if (vr_render_batch(tree.device, n, cams, &copt, frames, stream) != VR_OK) {
+            fprintf(stderr, "ERROR: %s\n", vr_last_error());
+            return 1;
+        }
+        if (!out_dir.empty()) {
+            for (int i = 0; i < n; ++i) {
+                if (vr_read_back(buf.data(), images[i], 0, width, height, stream) != VR_OK ||
+                    vr_stream_sync(stream) != VR_OK) {
+                    fprintf(stderr, "ERROR: %s\n", vr_last_error());
+                    return 1;
+                }
+                const std::string fpath = out_dir + "/" + basenames[first + i] + ".png";
+                internal::write_png_file(fpath, buf.data(), width, height);
+            }
+        }
+    }
+    HIP_OK(hipEventRecord(stop, stream));
+    HIP_OK(hipEventSynchronize(stop));
+    float milliseconds = 0;
+    HIP_OK(hipEventElapsedTime(&milliseconds, start, stop));
+    milliseconds = milliseconds / trans.size();
+
+    printf("%.10f ms per frame\n", milliseconds);
+    printf("%.10f fps\n", 1000.f / milliseconds);
+    printf("%.4f Mrays/s\n", (double)width * height / (milliseconds * 1e3));
+
+    for (void* p : images) HIP_OK(hipFree(p));
+    HIP_OK(hipStreamDestroy(stream));
+    return 0;
+}

@@ -1,0 +1,278 @@
+// npz.cpp -- .npy / .npz reader (see volrend/internal/npz.hpp).
+// Walks the ZIP central directory (robust against data descriptors and ZIP64 local
+// headers, both of which numpy's savez produces), inflates deflated members with zlib.
+#include "volrend/internal/npz.hpp"
+
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+namespace volrend {
+namespace internal {
+namespace {
+
+uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+uint32_t rd32(const uint8_t* p) {
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+uint64_t rd64(const uint8_t* p) { return (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32); }
+
+[[noreturn]] void fail(const std::string& what) { throw std::runtime_error("npz: " + what); }
+
+// header dict, e.g. {'descr': '<f2', 'fortran_order': False, 'shape': (3, 2, 2, 2), }
+void parse_header(const std::string& h, NpyArray& a) {
+    auto find_value = [&](const char* key) -> size_t {
+        const size_t k = h.find(key);
+        if (k == std::string::npos) fail(std::string("header lacks ") + key);
+        const size_t c = h.find(':', k);
+        if (c == std::string::npos) fail("malformed header");
+        return c + 1;
+    };
+    {  // descr
+        size_t p = find_value("'descr'");
+        const size_t q1 = h.find('\'', p);
+        const size_t q2 = h.find('\'', q1 + 1);
+        if (q1 == std::string::npos || q2 == std::string::npos) fail("malformed descr");
+        const std::string d = h.substr(q1 + 1, q2 - q1 - 1);  // like "<f2", "|u1", "<U4"
+        if (d.size() < 3) fail("unsupported dtype " + d);
+        if (d[0] == '>') fail("big-endian arrays are not supported");
+        a.kind = d[1];
+        const size_t n = (size_t)std::stoul(d.substr(2));
+        a.word_size = a.kind == 'U' ? n * 4 : n;  // numpy stores UCS4
+    }
+    {  // fortran_order
+        size_t p = find_value("'fortran_order'");
+        while (p < h.size() && h[p] == ' ') ++p;
+        a.fortran_order = h.compare(p, 4, "True") == 0;
+    }
+    {  // shape
+        size_t p = find_value("'shape'");
+        const size_t l = h.find('(', p), r = h.find(')', p);
+        if (l == std::string::npos || r == std::string::npos) fail("malformed shape");
+        a.shape.clear();
+        size_t i = l + 1;
+        while (i < r) {
+            while (i < r && (h[i] == ' ' || h[i] == ',')) ++i;
+            if (i >= r) break;
+            size_t j = i;
+            while (j < r && h[j] >= '0' && h[j] <= '9') ++j;
+            if (j == i) fail("malformed shape");
+            a.shape.push_back((size_t)std::stoull(h.substr(i, j - i)));
+            i = j;
+        }
+    }
+    a.num_vals = 1;
+    for (size_t s : a.shape) a.num_vals *= s;
+}
+
+// Parses the npy preamble; returns the offset of the raw data.
+size_t parse_npy_preamble(const uint8_t* b, size_t size, NpyArray& a) {
+    if (size < 10 || std::memcmp(b, "\x93NUMPY", 6) != 0) fail("not an npy stream");
+    const int major = b[6];
+    size_t hlen, off;
+    if (major == 1) {
+        hlen = rd16(b + 8);
+        off = 10;
+    } else {
+        if (size < 12) fail("truncated npy header");
+        hlen = rd32(b + 8);
+        off = 12;
+    }
+    if (off + hlen > size) fail("truncated npy header");
+    parse_header(std::string(reinterpret_cast<const char*>(b + off), hlen), a);
+    return off + hlen;
+}
+
+std::vector<uint8_t> read_file(const std::string& path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) fail("cannot open " + path);
+    const std::streamsize n = f.tellg();
+    f.seekg(0);
+    std::vector<uint8_t> buf((size_t)n);
+    if (n && !f.read(reinterpret_cast<char*>(buf.data()), n)) fail("cannot read " + path);
+    return buf;
+}
+
+struct Member {
+    std::string name;
+    uint16_t method;
+    uint64_t csize, usize, local_off;
+};
+
+std::vector<Member> central_directory(const uint8_t* b, size_t size) {
+    if (size < 22) fail("file too small for a zip archive");
+    // end of central directory record: scan backwards for its signature
+    size_t eocd = std::string::npos;
+    const size_t lo = size > 22 + 65535 ? size - 22 - 65535 : 0;
+    for (size_t i = size - 22 + 1; i-- > lo;) {
+        if (rd32(b + i) == 0x06054b50u) {
+            eocd = i;
+            break;
+        }
+    }
+    if (eocd == std::string::npos) fail("zip end-of-central-directory not found");
+    uint64_t n_entries = rd16(b + eocd + 10);
+    uint64_t cd_off = rd32(b + eocd + 16);
+    if (eocd >= 20 && rd32(b + eocd - 20) == 0x07064b50u) {  // ZIP64 locator
+        const uint64_t z64 = rd64(b + eocd - 20 + 8);
+        if (z64 + 56 > size || rd32(b + z64) != 0x06064b50u) fail("bad zip64 record");
+        n_entries = rd64(b + z64 + 32);
+        cd_off = rd64(b + z64 + 48);
+    }
+    std::vector<Member> out;
+    uint64_t p = cd_off;
+    for (uint64_t e = 0; e < n_entries; ++e) {
+        if (p + 46 > size || rd32(b + p) != 0x02014b50u) fail("bad central directory entry");
+        Member m;
+        m.method = rd16(b + p + 10);
+        m.csize = rd32(b + p + 20);
+        m.usize = rd32(b + p + 24);
+        const uint16_t fn = rd16(b + p + 28), ex = rd16(b + p + 30), cm = rd16(b + p + 32);
+        m.local_off = rd32(b + p + 42);
+        m.name.assign(reinterpret_cast<const char*>(b + p + 46), fn);
+        // ZIP64 extended information: only the saturated fields are present, in order
+        uint64_t q = p + 46 + fn;
+        const uint64_t qend = q + ex;
+        while (q + 4 <= qend) {
+            const uint16_t id = rd16(b + q), len = rd16(b + q + 2);
+            if (id == 0x0001) {
+                uint64_t r = q + 4;
+                if (m.usize == 0xFFFFFFFFu) { m.usize = rd64(b + r); r += 8; }
+                if (m.csize == 0xFFFFFFFFu) { m.csize = rd64(b + r); r += 8; }
+                if (m.local_off == 0xFFFFFFFFu) { m.local_off = rd64(b + r); r += 8; }
+            }
+            q += 4 + len;
+        }
+        out.push_back(std::move(m));
+        p += 46 + fn + ex + cm;
+    }
+    return out;
+}
+
+NpyArray load_member(const uint8_t* b, size_t size, const Member& m) {
+    if (m.local_off + 30 > size || rd32(b + m.local_off) != 0x04034b50u)
+        fail("bad local header for " + m.name);
+    const uint16_t fn = rd16(b + m.local_off + 26), ex = rd16(b + m.local_off + 28);
+    const uint64_t data_off = m.local_off + 30 + fn + ex;
+    if (data_off + m.csize > size) fail("member " + m.name + " exceeds the archive");
+    NpyArray a;
+    if (m.method == 0) {  // stored
+        const size_t pre = parse_npy_preamble(b + data_off, (size_t)m.csize, a);
+        const size_t want = a.num_vals * a.word_size;
+        if (pre + want > m.csize) fail("member " + m.name + " is truncated");
+        a.data_holder.assign(b + data_off + pre, b + data_off + pre + want);
+    } else if (m.method == 8) {  // deflate: inflate the whole member, then strip the preamble
+        std::vector<uint8_t> raw((size_t)m.usize);
+        z_stream zs;
+        std::memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -MAX_WBITS) != Z_OK) fail("inflateInit2 failed");
+        // zlib counts in 32-bit uInt: feed and drain in bounded slices
+        uint64_t in_done = 0, out_done = 0;
+        int rc = Z_OK;
+        while (rc != Z_STREAM_END) {
+            if (zs.avail_in == 0 && in_done < m.csize) {
+                const uint64_t n = std::min<uint64_t>(m.csize - in_done, 1u << 30);
+                zs.next_in = const_cast<Bytef*>(b + data_off + in_done);
+                zs.avail_in = (uInt)n;
+                in_done += n;
+            }
+            if (zs.avail_out == 0 && out_done < m.usize) {
+                const uint64_t n = std::min<uint64_t>(m.usize - out_done, 1u << 30);
+                zs.next_out = raw.data() + out_done;
+                zs.avail_out = (uInt)n;
+                out_done += n;
+            }
+            rc = inflate(&zs, Z_NO_FLUSH);
+            if (rc != Z_OK && rc != Z_STREAM_END) {
+                inflateEnd(&zs);
+                fail("inflate failed for " + m.name);
+            }
+            if (rc == Z_OK && zs.avail_in == 0 && in_done >= m.csize && zs.avail_out != 0) break;
+        }
+        inflateEnd(&zs);
+        const size_t pre = parse_npy_preamble(raw.data(), raw.size(), a);
+        const size_t want = a.num_vals * a.word_size;
+        if (pre + want > raw.size()) fail("member " + m.name + " is truncated");
+        raw.erase(raw.begin(), raw.begin() + (long)pre);
+        raw.resize(want);
+        a.data_holder = std::move(raw);
+    } else {
+        fail("unsupported zip compression method for " + m.name);
+    }
+    return a;
+}
+
+}  // namespace
+
+double NpyArray::as_double(size_t i) const {
+    if (i >= num_vals) throw std::out_of_range("npy index");
+    const uint8_t* p = data_holder.data() + i * word_size;
+    switch (kind) {
+        case 'f':
+            if (word_size == 4) { float v; std::memcpy(&v, p, 4); return v; }
+            if (word_size == 8) { double v; std::memcpy(&v, p, 8); return v; }
+            break;
+        case 'i':
+            if (word_size == 1) return (int8_t)p[0];
+            if (word_size == 2) { int16_t v; std::memcpy(&v, p, 2); return v; }
+            if (word_size == 4) { int32_t v; std::memcpy(&v, p, 4); return v; }
+            if (word_size == 8) { int64_t v; std::memcpy(&v, p, 8); return (double)v; }
+            break;
+        case 'u':
+        case 'b':
+            if (word_size == 1) return p[0];
+            if (word_size == 2) { uint16_t v; std::memcpy(&v, p, 2); return v; }
+            if (word_size == 4) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+            if (word_size == 8) { uint64_t v; std::memcpy(&v, p, 8); return (double)v; }
+            break;
+        default:
+            break;
+    }
+    throw std::runtime_error("npz: array is not numeric");
+}
+
+std::string NpyArray::as_string() const {
+    std::string s;
+    if (kind == 'U') {  // UCS4 little-endian: keep the low byte of each code point
+        for (size_t i = 0; i + 3 < data_holder.size(); i += 4)
+            if (data_holder[i]) s.push_back((char)data_holder[i]);
+    } else {
+        for (uint8_t c : data_holder)
+            if (c) s.push_back((char)c);
+    }
+    return s;
+}
+
+NpyArray npy_parse(const uint8_t* bytes, size_t size) {
+    NpyArray a;
+    const size_t pre = parse_npy_preamble(bytes, size, a);
+    const size_t want = a.num_vals * a.word_size;
+    if (pre + want > size) fail("npy stream is truncated");
+    a.data_holder.assign(bytes + pre, bytes + pre + want);
+    return a;
+}
+
+NpyArray npy_load(const std::string& path) {
+    const std::vector<uint8_t> buf = read_file(path);
+    return npy_parse(buf.data(), buf.size());
+}
+
+NpzFile npz_load_mem(const uint8_t* bytes, size_t size) {
+    NpzFile out;
+    for (const Member& m : central_directory(bytes, size)) {
+        std::string key = m.name;
+        if (key.size() > 4 && key.compare(key.size() - 4, 4, ".npy") == 0) key.resize(key.size() - 4);
+        out.emplace(std::move(key), load_member(bytes, size, m));
+    }
+    return out;
+}
+
+NpzFile npz_load(const std::string& path) {
+    const std::vector<uint8_t> buf = read_file(path);
+    return npz_load_mem(buf.data(), buf.size());
+}
+
+}  // namespace internal
+}  // namespace volrend
