@@ -130,12 +130,21 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # VOLREND_FORCE_GATHER=1: run the tile-shard + RCCL gather path even with one rank
+    force_gather = os.environ.get("VOLREND_FORCE_GATHER", "0") == "1"
+    use_dist = world > 1 or force_gather
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        # RCCL writes its version banner to stdout; stdout carries the ONE JSON line
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/volrend_bench_rccl.%h.%p.log")
+        if world == 1:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     cfg = synth.CONFIGS[args.config]
@@ -156,19 +165,21 @@ def main():
     if args.tune:
         api.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
 
-    B = max(1, min(args.batch, 16))
+    # per-GPU work per launch shrinks with the tile shard: keep it up with more poses per launch
+    B = max(1, min(args.batch * world, 48))
     tile_h = max(8, (args.tile_rows // 8) * 8)
     tile_w = (W + 7) // 8 * 8
     shard = api.TileShard(tile_w, tile_h, rank, world, compact=True)
     # double-buffered outputs: launch j writes set j % 2
     frames = [[torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
               for _ in range(2)]
-    nbytes = api.compact_bytes(W, H, shard) if world > 1 else 0
+    sharded = use_dist
+    nbytes = api.compact_bytes(W, H, shard) if sharded else 0
     pipe = GatherPipeline(
         dist, rank, world,
         lambda: torch.zeros((B, max(nbytes, 1)), dtype=torch.uint8, device=dev),
         lambda: [torch.zeros((B, max(nbytes, 1)), dtype=torch.uint8, device=dev)
-                 for _ in range(world)])
+                 for _ in range(world)], force_collective=force_gather)
 
     def pose_of(step):
         return transforms[step % len(transforms)]
@@ -181,7 +192,7 @@ def main():
         ev = timing["events"][j] if timing["events"] else None
         if ev is not None:
             ev[0].record(stream)
-        if world == 1:
+        if not sharded:
             api.launch_renderer_batch(tree, cam, tr, opts, frames[j % 2][:n], stream, True,
                                       fp_mode=fp_mode)
         else:
@@ -191,7 +202,7 @@ def main():
             ev[1].record(stream)
 
     def assemble(j, glist, n):
-        if world == 1:
+        if not sharded:
             return  # frames were rendered in place
         for i in range(n):  # rank-major stack of frame i's compact buffers -> frame
             api.assemble_tiles(frames[j % 2][i], torch.stack([g[i] for g in glist]), W, H, shard,
@@ -240,10 +251,24 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
 
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # self-check of the sharded path (untimed): the gathered + de-interleaved frame must equal
+    # the frame rendered by one GPU alone, byte for byte
+    shard_ok = None
+    if sharded:
+        run(1, 0)
+        torch.cuda.synchronize()
+        if rank == 0:
+            direct = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+            cam.transform = pose_of(0)
+            api.launch_renderer(tree, cam, opts, direct, None, stream, True, fp_mode=fp_mode)
+            torch.cuda.synchronize()
+            shard_ok = bool(torch.equal(direct, frames[0][0]))
+            log(f"[bench] sharded frame == single-GPU frame: {shard_ok}")
 
     kern_ms = [a.elapsed_time(b) for a, b in events]
     kern_total_s = float(np.sum(kern_ms)) / 1e3
@@ -275,6 +300,7 @@ def main():
                             f"fx=fy={focal}, 200-pose orbit, default RenderOptions",
                 "fp_mode": args.fp,
                 "frames_per_launch": B,
+                "sharded_frame_matches_single_gpu": shard_ok,
                 "parallelism": "single GPU" if world == 1 else
                                f"screen tiles {tile_w}x{tile_h} round-robin over {world} GPUs, "
                                f"tree replicated, one RCCL gather of RGBA8 to rank 0 per launch",
@@ -300,7 +326,7 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     tree.free_device()

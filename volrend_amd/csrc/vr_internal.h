@@ -8,7 +8,7 @@
 
 namespace vr {
 
-constexpr int kMaxBatch = 16;  // frames per launch (VR_MAX_BATCH)
+constexpr int kMaxBatch = 48;  // frames per launch (VR_MAX_BATCH); the table must fit the 4 KB kernarg
 
 // Per-frame part of a launch: pose and buffers.  Lives in device memory (one
 // small table per launch slot) because lanes of one wave may hold rays of

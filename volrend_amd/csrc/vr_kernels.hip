@@ -209,11 +209,16 @@ __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, float
         node = 0;
         l = 0;
     }
+    // One dependent 4-byte gather per level: slot = the three level-l digits; the node
+    // array is < 4 GB, so a 32-bit byte offset off the (scalar) base is enough.
+    const char* nodes_base = reinterpret_cast<const char*>(p.nodes);
     uint32_t slot, w;
     for (;; ++l) {
-        const int sh = 23 - l;
-        slot = (((ux >> sh) & 1u) << 2) | (((uy >> sh) & 1u) << 1) | ((uz >> sh) & 1u);
-        w = p.nodes[(uint64_t)node * 8u + slot];
+        const uint32_t sh = (uint32_t)(23 - l);
+        slot = (__builtin_amdgcn_ubfe(ux, sh, 1u) << 2) | (__builtin_amdgcn_ubfe(uy, sh, 1u) << 1) |
+               __builtin_amdgcn_ubfe(uz, sh, 1u);
+        const uint32_t byte_off = (node * 8u + slot) * 4u;
+        w = *reinterpret_cast<const uint32_t*>(nodes_base + byte_off);
         if ((w & kLeafBit) || l >= 23) break;
         node = w;
     }
@@ -591,6 +596,20 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
 // ---------------------------------------------------------------------------
 constexpr int kRayWords = 15;
 constexpr int kRing = 128;   // capacity; at most 127 items are ever outstanding
+constexpr int kHalf = 32;    // records staged per pass of the cooperative loader
+
+// Cooperative, line-coalesced record loads: a record of V 16-byte vectors is fetched by a
+// group of L = pow2(V) adjacent lanes (one cache line per group instead of one line per
+// lane and vector), parked in LDS with an odd row pitch (bank-conflict-free 128-bit
+// reads) and picked up whole by the lane that shades it.
+template <int BASIS>
+struct Coop {
+    static constexpr bool kEnabled = BASIS > 1;
+    static constexpr int kVec = RecTraits<BASIS>::kDwords / 4;                  // V
+    static constexpr int kLanes = kVec <= 2 ? 2 : kVec <= 4 ? 4 : kVec <= 8 ? 8 : 16;  // L
+    static constexpr int kPerInstr = kWave / kLanes;                            // records per load
+    static constexpr int kRow = (kVec | 1) * 16;                                // bytes, odd * 16
+};
 constexpr int kOwnerQ = 4;   // outstanding items per ray (8-bit ring positions in one VGPR)
 
 template <int FMA, int BASIS, int MODE>
@@ -605,7 +624,12 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
     __shared__ uint32_t it_leaf[kRing];
     __shared__ float it_w[kRing];
     __shared__ uint32_t it_own[kRing];
-    __shared__ float res[3 * kRing];
+    // `stage` (SH records in flight between the coalesced loads and their consumer lanes)
+    // and `res` (the colour contributions) are never live at the same time: one region.
+    constexpr int kStageWords = Coop<BASIS>::kEnabled ? kHalf * Coop<BASIS>::kRow / 4 : 0;
+    constexpr int kScratchWords = kStageWords > 3 * kRing ? kStageWords : 3 * kRing;
+    __shared__ __attribute__((aligned(16))) uint32_t scratch[kScratchWords];
+    float* const res = reinterpret_cast<float*>(scratch);
 
     const int lane = threadIdx.x & (kWave - 1);
     Ray ray;
@@ -649,12 +673,47 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
             st_shade_r++;
             st_shade_l += (uint32_t)n;
         }
+        Record<BASIS> rec;
+        if (Coop<BASIS>::kEnabled) {
+            using CP = Coop<BASIS>;
+            const int grp = lane / CP::kLanes, vec = lane % CP::kLanes;
+#pragma unroll
+            for (int half = 0; half < kWave / kHalf; ++half) {
+                if (half * kHalf < n) {  // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < kHalf / CP::kPerInstr; ++i) {
+                        const int r = i * CP::kPerInstr + grp;  // record within this half
+                        const int item = half * kHalf + r;
+                        if (item < n && vec < CP::kVec) {
+                            const uint32_t leaf = it_leaf[(ring_head + (uint32_t)item) & (kRing - 1)];
+                            const uint4 q = reinterpret_cast<const uint4*>(
+                                p.leaves + (uint64_t)leaf * (uint32_t)p.leaf_stride_h)[vec];
+                            *reinterpret_cast<uint4*>(
+                                reinterpret_cast<char*>(scratch) + r * CP::kRow + vec * 16) = q;
+                        }
+                    }
+                    __syncthreads();  // the half is staged
+                    if ((lane / kHalf) == half && lane < n) {
+                        const char* row =
+                            reinterpret_cast<const char*>(scratch) + (lane % kHalf) * CP::kRow;
+#pragma unroll
+                        for (int v = 0; v < CP::kVec; ++v) {
+                            const uint4 q = *reinterpret_cast<const uint4*>(row + v * 16);
+                            rec.w[4 * v + 0] = q.x;
+                            rec.w[4 * v + 1] = q.y;
+                            rec.w[4 * v + 2] = q.z;
+                            rec.w[4 * v + 3] = q.w;
+                        }
+                    }
+                    __syncthreads();  // the staging area may be overwritten
+                }
+            }
+        }
         if (lane < n) {
             const uint32_t j = (ring_head + (uint32_t)lane) & (kRing - 1);
             const float weight = it_w[j];
             const uint32_t own = it_own[j];
-            Record<BASIS> rec;
-            load_record<BASIS>(p, it_leaf[j], rec);
+            if (!Coop<BASIS>::kEnabled) load_record<BASIS>(p, it_leaf[j], rec);
             if (HAS_BASIS) {
                 float b[NB];
 #pragma unroll
@@ -1197,7 +1256,7 @@ hipError_t launch_render(const KParams& p, const FrameTable& tbl, int fp_mode, i
     }
     // persistent march grid: enough waves to fill the chip, but no more than one per
     // ~256 pixels so that small launches still rebalance through the ray queue
-    int64_t want = total_blocks / 4;
+    int64_t want = total_blocks / 2;  // about one wave per 64 rays that enter the volume
     if (want < 256) want = 256;
     if (want > n_waves) want = n_waves;
     if (want > total_blocks) want = total_blocks;

@@ -14,10 +14,14 @@ from __future__ import annotations
 
 
 class GatherPipeline:
-    def __init__(self, dist, rank: int, world: int, make_buffer, make_gather_list):
+    def __init__(self, dist, rank: int, world: int, make_buffer, make_gather_list,
+                 force_collective: bool = False):
         """``make_buffer()`` -> this rank's compact buffer (tensor) for one launch;
         ``make_gather_list()`` -> list of ``world`` tensors like it (rank 0 only)."""
         self.dist, self.rank, self.world = dist, rank, world
+        # world == 1 normally skips the collective; force_collective keeps it (tests the
+        # RCCL path on a single-GPU box)
+        self.collective = world > 1 or force_collective
         self.bufs = [make_buffer() for _ in range(2)]
         self.gathered = [make_gather_list() if rank == 0 else None for _ in range(2)]
         self.works = {}
@@ -29,7 +33,7 @@ class GatherPipeline:
     def submit(self, j: int, n: int) -> None:
         """Launch j has been enqueued into buffer(j): start its gather."""
         self.sizes[j] = n
-        if self.world == 1:
+        if not self.collective:
             return
         self.works[j] = self.dist.gather(self.bufs[j % 2], self.gathered[j % 2], dst=0,
                                          async_op=True)
@@ -40,10 +44,10 @@ class GatherPipeline:
         if j not in self.sizes:
             return
         n = self.sizes.pop(j)
-        if self.world > 1:
+        if self.collective:
             self.works.pop(j).wait()
         if self.rank == 0:
-            assemble(j, self.gathered[j % 2] if self.world > 1 else [self.bufs[j % 2]], n)
+            assemble(j, self.gathered[j % 2] if self.collective else [self.bufs[j % 2]], n)
 
     def run(self, n_steps: int, batch: int, render, assemble, first_step: int = 0) -> int:
         """render(j, first_step, n, buffer) enqueues one launch; returns launches done."""
