@@ -104,12 +104,12 @@ def cpu_baseline(tree, transforms, width, height, focal, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=208)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--config", default="C1", choices=["C0", "C1", "C2", "C3"])
     ap.add_argument("--fp", default="strict", choices=["strict", "fma"])
     ap.add_argument("--tile-rows", type=int, default=8, help="rows per interleaved screen tile")
-    ap.add_argument("--batch", type=int, default=16,
+    ap.add_argument("--batch", type=int, default=64,
                     help="poses per launch (vr_render_batch); steps must be a multiple")
     ap.add_argument("--tune", default="", help="k=v,... scheduling knobs (march_max, refill_min, waves_per_cu)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,7 +166,7 @@ def main():
         api.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
 
     # per-GPU work per launch shrinks with the tile shard: keep it up with more poses per launch
-    B = max(1, min(args.batch * world, 48))
+    B = max(1, min(args.batch * world, 128))
     tile_h = max(8, (args.tile_rows // 8) * 8)
     tile_w = (W + 7) // 8 * 8
     shard = api.TileShard(tile_w, tile_h, rank, world, compact=True)

@@ -183,7 +183,7 @@ int vr_render(vr_tree_t tree, const VrCamera* cam, const VrRenderOptions* opt,
  * known up front): cams[i] -> frames[i].  All entries must share image size,
  * intrinsics, layout, sharding and fp_mode; only the pose and the buffers differ.
  * A single 800x800 frame cannot fill 256 CUs; a batch can.  1 <= n <= VR_MAX_BATCH. */
-#define VR_MAX_BATCH 48
+#define VR_MAX_BATCH 128
 int vr_render_batch(vr_tree_t tree, int n_frames, const VrCamera* cams,
                     const VrRenderOptions* opt, const VrFrame* frames, void* stream);
 /* Scheduling knobs of the persistent kernel ("march_max", "refill_min",

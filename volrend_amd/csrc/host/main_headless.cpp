@@ -97,7 +97,7 @@ int main(int argc, char* argv[]) {
     args.add("reverse_yz", 'r', true, "", "use OpenCV camera space convention instead of NeRF");
     args.add("scale", 0, false, "1.0", "scaling to apply to image");
     args.add("max_imgs", 0, false, "0", "max images to render, default no limit");
-    args.add("batch", 0, false, "16", "poses per launch (1..48)");
+    args.add("batch", 0, false, "16", "poses per launch (1..128)");
     args.add("fp", 0, false, "strict", "floating-point model: strict | fma");
     try {
         internal::parse_options(args, argc, argv);

@@ -443,9 +443,6 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     if (f->rank < 0 || f->rank >= world)
         return fail(VR_ERR_INVALID_ARGUMENT, "rank %d outside world %d", f->rank, world);
 
-    vr::FrameTable tbl;
-    memset(&tbl, 0, sizeof(tbl));
-    tbl.n = n_frames;
     bool instrumented = false;
     for (int i = 0; i < n_frames; ++i) {
         const VrFrame& fi = frames[i];
@@ -459,11 +456,6 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
             fi.tile_w != f->tile_w || fi.tile_h != f->tile_h || fi.rank != f->rank ||
             fi.world != f->world || fi.fp_mode != f->fp_mode)
             return fail(VR_ERR_INVALID_ARGUMENT, "frame %d: layout/shard/fp_mode differ within the batch", i);
-        memcpy(tbl.f[i].xf, ci.transform, sizeof(tbl.f[i].xf));
-        tbl.f[i].rgba = static_cast<uint8_t*>(fi.rgba);
-        tbl.f[i].accum = fi.accum;
-        tbl.f[i].depth = fi.depth;
-        tbl.f[i].counters = reinterpret_cast<unsigned long long*>(fi.counters);
         instrumented = instrumented || fi.counters != nullptr;
     }
 
@@ -549,7 +541,22 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.ray_buf_rw = t->slot_rays[slot];
     k.ray_buf = k.ray_buf_rw;
 
-    HIP_TRY(vr::launch_render(k, tbl, f->fp_mode, t->n_cus * tn.waves_per_cu,
+    // frame table -> device memory, kTableChunk poses per (tiny) kernel
+    for (int first = 0; first < n_frames; first += vr::kTableChunk) {
+        vr::FrameTable tbl;
+        memset(&tbl, 0, sizeof(tbl));
+        tbl.first = first;
+        tbl.n = n_frames - first < vr::kTableChunk ? n_frames - first : vr::kTableChunk;
+        for (int i = 0; i < tbl.n; ++i) {
+            memcpy(tbl.f[i].xf, cams[first + i].transform, sizeof(tbl.f[i].xf));
+            tbl.f[i].rgba = static_cast<uint8_t*>(frames[first + i].rgba);
+            tbl.f[i].accum = frames[first + i].accum;
+            tbl.f[i].depth = frames[first + i].depth;
+            tbl.f[i].counters = reinterpret_cast<unsigned long long*>(frames[first + i].counters);
+        }
+        HIP_TRY(vr::launch_prepare(k, tbl, static_cast<hipStream_t>(stream)));
+    }
+    HIP_TRY(vr::launch_render(k, f->fp_mode, t->n_cus * tn.waves_per_cu,
                               static_cast<hipStream_t>(stream)));
     return VR_OK;
 }

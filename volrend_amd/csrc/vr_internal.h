@@ -8,7 +8,8 @@
 
 namespace vr {
 
-constexpr int kMaxBatch = 48;  // frames per launch (VR_MAX_BATCH); the table must fit the 4 KB kernarg
+constexpr int kMaxBatch = 128;   // frames per launch (VR_MAX_BATCH)
+constexpr int kTableChunk = 48;  // frames per prepare_launch_kernel call (4 KB kernarg limit)
 
 // Per-frame part of a launch: pose and buffers.  Lives in device memory (one
 // small table per launch slot) because lanes of one wave may hold rays of
@@ -22,8 +23,9 @@ struct FrameDesc {
 };
 
 struct FrameTable {
+    int32_t first;  // index of f[0] in the device table
     int32_t n;
-    FrameDesc f[kMaxBatch];
+    FrameDesc f[kTableChunk];
 };
 
 // Everything else the render kernel needs, passed BY VALUE as the kernel argument
@@ -91,8 +93,8 @@ struct KParams {
 };
 
 // vr_kernels.hip
-hipError_t launch_render(const KParams& p, const FrameTable& tbl, int fp_mode, int n_waves,
-                         hipStream_t stream);
+hipError_t launch_prepare(const KParams& p, const FrameTable& tbl, hipStream_t stream);
+hipError_t launch_render(const KParams& p, int fp_mode, int n_waves, hipStream_t stream);
 hipError_t launch_assemble(uint8_t* frame, int64_t pitch, const uint8_t* gathered, int width,
                            int height, int tile_w, int tile_h, int world, hipStream_t stream);
 hipError_t launch_probe(const KParams& p, const float probe[3], float* out_dev,

@@ -1038,8 +1038,8 @@ __global__ __launch_bounds__(kWave* kGenWaves) void raygen_kernel(const KParams 
 __global__ void prepare_launch_kernel(FrameTable tbl, FrameDesc* frames, uint32_t* queue_head,
                                       uint32_t* ray_count) {
     const int i = threadIdx.x;
-    if (i < tbl.n) frames[i] = tbl.f[i];
-    if (i == 0) {
+    if (i < tbl.n) frames[tbl.first + i] = tbl.f[i];
+    if (i == 0 && tbl.first == 0) {
         *queue_head = 0u;
         *ray_count = 0u;
     }
@@ -1236,12 +1236,15 @@ hipError_t launch_fp(const KParams& p, dim3 grid, dim3 block, hipStream_t s) {
 
 }  // namespace
 
-hipError_t launch_render(const KParams& p, const FrameTable& tbl, int fp_mode, int n_waves,
-                         hipStream_t stream) {
-    if (p.n_wave_blocks <= 0 || tbl.n <= 0) return hipSuccess;
+hipError_t launch_prepare(const KParams& p, const FrameTable& tbl, hipStream_t stream) {
     hipLaunchKernelGGL(prepare_launch_kernel, dim3(1), dim3(64), 0, stream, tbl,
                        const_cast<FrameDesc*>(p.frames), p.queue_head, p.ray_count_rw);
-    const int64_t total_blocks = p.n_wave_blocks * tbl.n;
+    return hipGetLastError();
+}
+
+hipError_t launch_render(const KParams& p, int fp_mode, int n_waves, hipStream_t stream) {
+    if (p.n_wave_blocks <= 0 || p.n_frames <= 0) return hipSuccess;
+    const int64_t total_blocks = p.n_wave_blocks * p.n_frames;
     {   // ray generation: kGenWaves wave blocks (8x8 pixels each) per workgroup
         const dim3 ggrid((unsigned)((total_blocks + kGenWaves - 1) / kGenWaves));
         const dim3 gblock(kWave * kGenWaves);
@@ -1266,7 +1269,7 @@ hipError_t launch_render(const KParams& p, const FrameTable& tbl, int fp_mode, i
                                               : launch_fp<0>(p, grid, block, stream);
     if (e != hipSuccess || !p.enable_probe || p.probe_disp_size <= 0) return e;
     const int side = p.probe_disp_size + 5;
-    const dim3 pgrid((unsigned)((side * side + 255) / 256), (unsigned)tbl.n);
+    const dim3 pgrid((unsigned)((side * side + 255) / 256), (unsigned)p.n_frames);
     if (fp_mode == VR_FP_FMA)
         hipLaunchKernelGGL(probe_overlay_kernel<1>, pgrid, dim3(256), 0, stream, p);
     else
