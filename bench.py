@@ -280,7 +280,8 @@ def main():
         mrays = rays_total / elapsed / 1e6
         achieved = alg_bytes_per_launch / kern_mean_s / 1e9
         result = {
-            "metric": "Mrays/s at 800x800, NeRF-synthetic-like lego SH16 (synthetic C1)",
+            "metric": f"Mrays/s at {W}x{H}, NeRF-synthetic-like {cfg['fmt']}{cfg['basis_dim']} "
+                      f"(synthetic {args.config})",
             "value": round(mrays, 3),
             "unit": "Mrays/s",
             "fps": round(K / elapsed, 3),
@@ -312,7 +313,9 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": None,
-                "kernel": "vr::render_kernel<fp, SH16, FAST> (persistent, %d frames per launch)" % B,
+                "kernel": f"vr::render_kernel<{args.fp}, {cfg['fmt']}{cfg['basis_dim']}, FAST> "
+                          f"(persistent march/shade, {B} frames per launch; the launch also "
+                          f"runs prepare_launch_kernel + raygen_kernel, ~3 % of its time)",
                 "kernel_ms_mean": round(kern_mean_s * 1e3, 5),
                 "kernel_ms_per_frame": round(kern_total_s / K * 1e3, 5),
                 "alg_bytes_per_launch": int(alg_bytes_per_launch),

@@ -8,7 +8,7 @@ TAG=${1:-run}; shift || true
 OUT=gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 16 --warmup 8 --no-cpu-baseline $*"
+ARGS="--steps 128 --warmup 64 --no-cpu-baseline $*"
 GROUPS_TO_RUN=${PMC_GROUPS:-"sq1 sq2"}
 declare -A G
 G[sq1]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY"
@@ -16,7 +16,8 @@ G[sq2]="SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_V
 G[ta]="TA_BUSY_avr TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum"
 G[tcc]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
 G[fetch]="FETCH_SIZE GRBM_GUI_ACTIVE"
-G[write]="WRITE_SIZE TCC_EA0_RDREQ_32B_sum"
+G[write]="WRITE_SIZE"
+G[rdsize]="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
 G[tlb]="TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_TCC_READ_REQ_LATENCY_sum"
 for g in $GROUPS_TO_RUN; do
   ( cd /tmp && timeout 240 rocprofv3 --kernel-trace --pmc ${G[$g]} -d "$GRAFT_REPO_ROOT/$OUT" -o $g --output-format csv -- \
