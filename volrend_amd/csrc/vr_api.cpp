@@ -34,6 +34,7 @@ struct Tuning {
     int refill_min = 16;
     int waves_per_cu = 16;
     int shade_min = 48;
+    int frame_minor = 1;
 };
 Tuning& tuning() {
     static Tuning tn = [] {
@@ -42,6 +43,7 @@ Tuning& tuning() {
         if (const char* e = getenv("VR_REFILL_MIN")) x.refill_min = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_WAVES_PER_CU")) x.waves_per_cu = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_SHADE_MIN")) x.shade_min = atoi(e) < 1 ? 1 : atoi(e);
+        if (const char* e = getenv("VR_FRAME_MINOR")) x.frame_minor = atoi(e) != 0;
         return x;
     }();
     return tn;
@@ -417,6 +419,7 @@ int vr_set_tuning(const char* key, int value) {
     else if (!strcmp(key, "refill_min")) tn.refill_min = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "waves_per_cu")) tn.waves_per_cu = value < 1 ? 1 : (value > 32 ? 32 : value);
     else if (!strcmp(key, "shade_min")) tn.shade_min = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (!strcmp(key, "frame_minor")) tn.frame_minor = value != 0;
     else return fail(VR_ERR_INVALID_ARGUMENT, "unknown tuning key '%s'", key);
     return VR_OK;
 }
@@ -516,6 +519,7 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.march_max = tn.march_max;
     k.refill_min = tn.refill_min;
     k.shade_min = tn.shade_min;
+    k.frame_minor = tn.frame_minor;
     // launch slot: frame table + queue head in device memory (ring, see VrTreeOpaque)
     const unsigned slot = t->launch_seq.fetch_add(1) % kLaunchSlots;
     k.frames = t->slot_frames + (size_t)slot * vr::kMaxBatch;

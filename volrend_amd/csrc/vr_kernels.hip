@@ -399,11 +399,20 @@ struct PixelRef {
 
 __device__ __forceinline__ PixelRef locate(const KParams& p, uint32_t id) {
     PixelRef r;
-    const uint32_t per_frame = (uint32_t)p.n_wave_blocks * 64u;
-    r.frame = (int32_t)(id / per_frame);
-    const uint32_t rid = id - (uint32_t)r.frame * per_frame;
-    const int32_t wb = (int32_t)(rid >> 6);
-    const int32_t lane = (int32_t)(rid & 63u);
+    // Ray-id order: 8x8 pixel block major, FRAME minor (frame_minor = 1): the same pixel block
+    // of consecutive poses of the batch sits in consecutive ids, so rays that walk through
+    // (nearly) the same leaves are generated, queued and marched together and share
+    // cache lines.  frame_minor = 0 is plain frame-major order.
+    const uint32_t blk = id >> 6;
+    const int32_t lane = (int32_t)(id & 63u);
+    int32_t wb;
+    if (p.frame_minor) {
+        wb = (int32_t)(blk / (uint32_t)p.n_frames);
+        r.frame = (int32_t)(blk - (uint32_t)wb * (uint32_t)p.n_frames);
+    } else {
+        r.frame = (int32_t)(blk / (uint32_t)p.n_wave_blocks);
+        wb = (int32_t)(blk - (uint32_t)r.frame * (uint32_t)p.n_wave_blocks);
+    }
     // wave block -> local tile -> frame tile -> pixel
     r.k = wb / p.wblocks_per_tile;
     const int32_t sub = wb - r.k * p.wblocks_per_tile;
@@ -596,7 +605,10 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
 // ---------------------------------------------------------------------------
 constexpr int kRayWords = 15;
 constexpr int kRing = 128;   // capacity; at most 127 items are ever outstanding
-constexpr int kHalf = 32;    // records staged per pass of the cooperative loader
+#ifndef VR_STAGE_RECORDS
+#define VR_STAGE_RECORDS 32
+#endif
+constexpr int kHalf = VR_STAGE_RECORDS;  // records staged per pass of the cooperative loader
 
 // Cooperative, line-coalesced record loads: a record of V 16-byte vectors is fetched by a
 // group of L = pow2(V) adjacent lanes (one cache line per group instead of one line per
