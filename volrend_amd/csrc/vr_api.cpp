@@ -32,7 +32,7 @@ int fail(int code, const char* fmt, ...) {
 struct Tuning {
     int march_max = 2;
     int refill_min = 16;
-    int waves_per_cu = 16;
+    int waves_per_cu = 20;
     int shade_min = 48;
     int frame_minor = 1;
 };

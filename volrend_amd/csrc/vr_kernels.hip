@@ -23,7 +23,7 @@ constexpr int kWave = 64;
 #define VR_ABLATE 0  // != 0: timing experiments that break the results (never shipped)
 #endif
 #ifndef VR_MIN_WAVES_PER_EU
-#define VR_MIN_WAVES_PER_EU 4
+#define VR_MIN_WAVES_PER_EU 5
 #endif
 constexpr int kMaxIter = 1 << 22;  // guard against step_size <= 0 (upstream would spin forever)
 
@@ -606,7 +606,7 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
 constexpr int kRayWords = 15;
 constexpr int kRing = 128;   // capacity; at most 127 items are ever outstanding
 #ifndef VR_STAGE_RECORDS
-#define VR_STAGE_RECORDS 32
+#define VR_STAGE_RECORDS 16
 #endif
 constexpr int kHalf = VR_STAGE_RECORDS;  // records staged per pass of the cooperative loader
 
