@@ -275,6 +275,20 @@ def main():
     kern_mean_s = kern_total_s / n_launch
     alg_bytes_per_launch = alg_bytes_per_frame * K / n_launch
 
+    # HBM-side traffic: PMC counters need a rocprofv3 run of their own (tools/pmc.sh), so the
+    # bench reports the committed measurement of the same kernel/config, scaled to this
+    # launch size, and says where it comes from; null when nothing matches.
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if world == 1 and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("config") == args.config and tj.get("fp_mode") == args.fp:
+            traffic = int((tj["read_bytes_per_frame"] + tj["write_bytes_per_frame"]) *
+                          K / n_launch)
+            traffic_src = (f"profiles/r01_traffic.json (rocprofv3 --pmc passes at "
+                           f"{tj['frames_per_launch']} frames per launch, TCC_EA0_RDREQ_128B*128 "
+                           f"+ WRITE_SIZE; FETCH_SIZE under-counts this kernel 2x)")
+
     if rank == 0:
         rays_total = W * H * K
         mrays = rays_total / elapsed / 1e6
@@ -312,7 +326,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch (L2<->fabric reads+writes)",
+                "traffic_source": traffic_src,
                 "kernel": f"vr::render_kernel<{args.fp}, {cfg['fmt']}{cfg['basis_dim']}, FAST> "
                           f"(persistent march/shade, {B} frames per launch; the launch also "
                           f"runs prepare_launch_kernel + raygen_kernel, ~3 % of its time)",

@@ -693,10 +693,11 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
             for (int half = 0; half < kWave / kHalf; ++half) {
                 if (half * kHalf < n) {  // wave-uniform
 #pragma unroll
-                    for (int i = 0; i < kHalf / CP::kPerInstr; ++i) {
-                        const int r = i * CP::kPerInstr + grp;  // record within this half
+                    // (one instruction may cover more records than a pass stages)
+                    for (int i = 0; i < (kHalf + CP::kPerInstr - 1) / CP::kPerInstr; ++i) {
+                        const int r = i * CP::kPerInstr + grp;  // record within this pass
                         const int item = half * kHalf + r;
-                        if (item < n && vec < CP::kVec) {
+                        if (r < kHalf && item < n && vec < CP::kVec) {
                             const uint32_t leaf = it_leaf[(ring_head + (uint32_t)item) & (kRing - 1)];
                             const uint4 q = reinterpret_cast<const uint4*>(
                                 p.leaves + (uint64_t)leaf * (uint32_t)p.leaf_stride_h)[vec];
