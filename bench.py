@@ -116,6 +116,12 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: everything else that writes to fd 1 (RCCL prints
+    # its version banner there) is sent to stderr; the JSON goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -171,15 +177,23 @@ def main():
     tile_w = (W + 7) // 8 * 8
     shard = api.TileShard(tile_w, tile_h, rank, world, compact=True)
     # double-buffered outputs: launch j writes set j % 2
-    frames = [[torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
-              for _ in range(2)]
+    frame_sets = [torch.zeros((B, H, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+    frames = [[fs[i] for i in range(B)] for fs in frame_sets]
     sharded = use_dist
     nbytes = api.compact_bytes(W, H, shard) if sharded else 0
+    # rank 0 receives into ONE [world, B, nbytes] tensor per set (the gather list are its rows),
+    # so a single launch de-interleaves a whole batch
+    gather_sets = []
+
+    def make_gather_list():
+        g = torch.zeros((world, B, max(nbytes, 1)), dtype=torch.uint8, device=dev)
+        gather_sets.append(g)
+        return [g[r] for r in range(world)]
+
     pipe = GatherPipeline(
         dist, rank, world,
         lambda: torch.zeros((B, max(nbytes, 1)), dtype=torch.uint8, device=dev),
-        lambda: [torch.zeros((B, max(nbytes, 1)), dtype=torch.uint8, device=dev)
-                 for _ in range(world)], force_collective=force_gather)
+        make_gather_list, force_collective=force_gather)
 
     def pose_of(step):
         return transforms[step % len(transforms)]
@@ -204,9 +218,7 @@ def main():
     def assemble(j, glist, n):
         if not sharded:
             return  # frames were rendered in place
-        for i in range(n):  # rank-major stack of frame i's compact buffers -> frame
-            api.assemble_tiles(frames[j % 2][i], torch.stack([g[i] for g in glist]), W, H, shard,
-                               stream)
+        api.assemble_tiles_batch(frame_sets[j % 2], gather_sets[j % 2], n, W, H, shard, stream)
 
     def run(n_steps, first, events=None):
         timing["events"] = events
@@ -344,7 +356,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(stree, transforms, W, H, focal, args.cpu_budget)
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result), flush=True)
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -198,6 +198,14 @@ int vr_sched_stats(vr_tree_t tree, uint64_t out[8], int reset);
  * on the current device.  Writes the W x H frame. */
 int vr_assemble_tiles(void* frame_rgba, int64_t pitch, const void* gathered, int width,
                       int height, int tile_w, int tile_h, int world, void* stream);
+/* The same for n_frames at once (one launch): frame i is written at
+ * frames_rgba + i*frame_stride; rank r's COMPACT buffer of frame i is read at
+ * gathered + r*rank_stride + i*in_frame_stride -- e.g. a [world][n_frames][compact_bytes]
+ * gather result has rank_stride = n_frames*compact_bytes, in_frame_stride = compact_bytes. */
+int vr_assemble_tiles_batch(void* frames_rgba, int64_t frame_stride, int64_t pitch,
+                            const void* gathered, int64_t rank_stride, int64_t in_frame_stride,
+                            int n_frames, int width, int height, int tile_w, int tile_h, int world,
+                            void* stream);
 /* out_dev: device float[data_dim-1]; the lumisphere at opt->probe. */
 int vr_probe_coeffs(vr_tree_t tree, const VrRenderOptions* opt, float* out_dev, void* stream);
 /* Async D2H of a pitched RGBA8 frame into tightly packed host memory. */

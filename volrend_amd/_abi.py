@@ -82,6 +82,9 @@ PROTOTYPES = {
     "vr_sched_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 8), C.c_int]),
     "vr_assemble_tiles": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_void_p]),
+    "vr_assemble_tiles_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                          C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_void_p]),
     "vr_probe_coeffs": (C.c_int, [C.c_void_p, C.POINTER(VrRenderOptions), C.c_void_p, C.c_void_p]),
     "vr_read_back": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "vr_stream_sync": (C.c_int, [C.c_void_p]),

@@ -414,3 +414,15 @@ def assemble_tiles(frame, gathered, width: int, height: int, shard: TileShard, s
     _abi.check(_abi.lib().vr_assemble_tiles(_ptr(frame), pitch, _ptr(gathered), width, height,
                                             shard.tile_w, shard.tile_h, shard.world,
                                             _stream_ptr(stream)))
+
+
+def assemble_tiles_batch(frames, gathered, n_frames: int, width: int, height: int,
+                         shard: TileShard, stream=None) -> None:
+    """``frames``: contiguous device [n, H, W, 4] uint8; ``gathered``: contiguous device
+    [world, n_alloc, compact_bytes] (rank-major gather result, n_alloc >= n_frames).
+    One launch de-interleaves all frames."""
+    cb = compact_bytes(width, height, shard)
+    n_alloc = int(gathered.shape[1]) if hasattr(gathered, "shape") else n_frames
+    _abi.check(_abi.lib().vr_assemble_tiles_batch(
+        _ptr(frames), width * height * 4, 0, _ptr(gathered), n_alloc * cb, cb, n_frames, width,
+        height, shard.tile_w, shard.tile_h, shard.world, _stream_ptr(stream)))

@@ -572,14 +572,28 @@ int vr_render(vr_tree_t t, const VrCamera* cam, const VrRenderOptions* opt, cons
 
 int vr_assemble_tiles(void* frame_rgba, int64_t pitch, const void* gathered, int width, int height,
                       int tile_w, int tile_h, int world, void* stream) {
-    if (!frame_rgba || !gathered) return fail(VR_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (world < 1) world = 1;
+    const int64_t rank_bytes = vr_compact_bytes(width, height, tile_w, tile_h, world);
+    if (rank_bytes < 0) return VR_ERR_INVALID_ARGUMENT;
+    return vr_assemble_tiles_batch(frame_rgba, 0, pitch, gathered, rank_bytes, 0, 1, width, height,
+                                   tile_w, tile_h, world, stream);
+}
+
+int vr_assemble_tiles_batch(void* frames_rgba, int64_t frame_stride, int64_t pitch,
+                            const void* gathered, int64_t rank_stride, int64_t in_frame_stride,
+                            int n_frames, int width, int height, int tile_w, int tile_h, int world,
+                            void* stream) {
+    if (!frames_rgba || !gathered) return fail(VR_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (n_frames < 1) return fail(VR_ERR_INVALID_ARGUMENT, "n_frames must be positive");
     int tw, th, tx, ty;
     int rc = tile_geometry(width, height, tile_w, tile_h, &tw, &th, &tx, &ty);
     if (rc != VR_OK) return rc;
     if (world < 1) world = 1;
-    HIP_TRY(vr::launch_assemble(static_cast<uint8_t*>(frame_rgba), pitch ? pitch : (int64_t)width * 4,
-                                static_cast<const uint8_t*>(gathered), width, height, tw, th,
-                                world, static_cast<hipStream_t>(stream)));
+    HIP_TRY(vr::launch_assemble(static_cast<uint8_t*>(frames_rgba),
+                                pitch ? pitch : (int64_t)width * 4,
+                                static_cast<const uint8_t*>(gathered), width, height, tw, th, world,
+                                n_frames, frame_stride, rank_stride, in_frame_stride,
+                                static_cast<hipStream_t>(stream)));
     return VR_OK;
 }
 

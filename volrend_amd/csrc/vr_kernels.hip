@@ -1135,21 +1135,24 @@ __global__ void probe_kernel(const KParams p, float probe0, float probe1, float 
     for (int i = threadIdx.x; i < p.data_dim - 1; i += blockDim.x) out[i] = h2f(v[i]);
 }
 
-// De-interleave `world` gathered COMPACT buffers into the frame.
+// De-interleave `world` gathered COMPACT buffers into frames.  blockIdx.z = frame of the
+// batch; rank r's compact buffer of frame i starts at gathered + r*rank_stride + i*in_stride.
 __global__ void assemble_kernel(uint8_t* frame, int64_t pitch, const uint8_t* gathered, int width,
                                 int height, int tile_w, int tile_h, int tiles_x, int world,
-                                int64_t tiles_per_rank) {
+                                int64_t out_stride, int64_t rank_stride, int64_t in_stride) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= width || y >= height) return;
+    frame += (int64_t)blockIdx.z * out_stride;
+    gathered += (int64_t)blockIdx.z * in_stride;
     const int tx = x / tile_w, ty = y / tile_h;
     const int tile = ty * tiles_x + tx;
     const int rank = tile % world;
     const int64_t k = tile / world;
     const int lx = x - tx * tile_w, ly = y - ty * tile_h;
-    const int64_t src = ((rank * tiles_per_rank + k) * tile_w * tile_h + (int64_t)ly * tile_w + lx);
+    const int64_t src = (k * tile_w * tile_h + (int64_t)ly * tile_w + lx);
     *reinterpret_cast<uint32_t*>(frame + (int64_t)y * pitch + (int64_t)x * 4) =
-        reinterpret_cast<const uint32_t*>(gathered)[src];
+        reinterpret_cast<const uint32_t*>(gathered + (int64_t)rank * rank_stride)[src];
 }
 
 // ---------------------------------------------------------------------------
@@ -1291,14 +1294,14 @@ hipError_t launch_render(const KParams& p, int fp_mode, int n_waves, hipStream_t
 }
 
 hipError_t launch_assemble(uint8_t* frame, int64_t pitch, const uint8_t* gathered, int width,
-                           int height, int tile_w, int tile_h, int world, hipStream_t stream) {
-    const int tiles_x = (width + tile_w - 1) / tile_w, tiles_y = (height + tile_h - 1) / tile_h;
-    const int64_t n_tiles = (int64_t)tiles_x * tiles_y;
-    const int64_t tiles_per_rank = (n_tiles + world - 1) / world;
+                           int height, int tile_w, int tile_h, int world, int n_frames,
+                           int64_t out_stride, int64_t rank_stride, int64_t in_stride,
+                           hipStream_t stream) {
+    const int tiles_x = (width + tile_w - 1) / tile_w;
     const dim3 block(64, 4);
-    const dim3 grid((width + 63) / 64, (height + 3) / 4);
+    const dim3 grid((width + 63) / 64, (height + 3) / 4, n_frames);
     hipLaunchKernelGGL(assemble_kernel, grid, block, 0, stream, frame, pitch, gathered, width,
-                       height, tile_w, tile_h, tiles_x, world, tiles_per_rank);
+                       height, tile_w, tile_h, tiles_x, world, out_stride, rank_stride, in_stride);
     return hipGetLastError();
 }
 
