@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64,
                     help="poses per launch (vr_render_batch); steps must be a multiple")
     ap.add_argument("--tune", default="", help="k=v,... scheduling knobs (march_max, refill_min, waves_per_cu)")
+    ap.add_argument("--readback", action="store_true",
+                    help="also copy every frame to pinned host memory inside the timed region "
+                         "(the PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -215,8 +218,13 @@ def main():
         if ev is not None:
             ev[1].record(stream)
 
+    host_sets = ([torch.empty((B, H, W, 4), dtype=torch.uint8).pin_memory() for _ in range(2)]
+                 if args.readback else None)
+
     def assemble(j, glist, n):
         if not sharded:
+            if host_sets is not None:  # D2H of the batch, async on the render stream
+                host_sets[j % 2][:n].copy_(frame_sets[j % 2][:n], non_blocking=True)
             return  # frames were rendered in place
         api.assemble_tiles_batch(frame_sets[j % 2], gather_sets[j % 2], n, W, H, shard, stream)
 
@@ -327,6 +335,7 @@ def main():
                             f"fx=fy={focal}, 200-pose orbit, default RenderOptions",
                 "fp_mode": args.fp,
                 "frames_per_launch": B,
+                "pcie_inclusive": bool(args.readback),
                 "sharded_frame_matches_single_gpu": shard_ok,
                 "parallelism": "single GPU" if world == 1 else
                                f"screen tiles {tile_w}x{tile_h} round-robin over {world} GPUs, "

@@ -35,6 +35,7 @@ struct Tuning {
     int waves_per_cu = 20;
     int shade_min = 48;
     int frame_minor = 1;
+    int xcd_queues = 1;
 };
 Tuning& tuning() {
     static Tuning tn = [] {
@@ -44,6 +45,7 @@ Tuning& tuning() {
         if (const char* e = getenv("VR_WAVES_PER_CU")) x.waves_per_cu = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_SHADE_MIN")) x.shade_min = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_FRAME_MINOR")) x.frame_minor = atoi(e) != 0;
+        if (const char* e = getenv("VR_XCD_QUEUES")) x.xcd_queues = atoi(e) != 0;
         return x;
     }();
     return tn;
@@ -61,6 +63,7 @@ Tuning& tuning() {
 }  // namespace
 
 constexpr unsigned kLaunchSlots = 4;
+constexpr unsigned kSlotWords = 160;  // [0] ray count, [16 + 16*x] queue head x (x < 8)
 
 struct VrTreeOpaque {
     int device = 0;
@@ -283,7 +286,8 @@ int vr_tree_upload(const VrTreeDesc* d, vr_tree_t* out) {
     if (e == hipSuccess) e = hipMalloc((void**)&t->probe_buf, sizeof(float) * (size_t)d->data_dim);
     if (e == hipSuccess)
         e = hipMalloc((void**)&t->slot_frames, sizeof(vr::FrameDesc) * vr::kMaxBatch * kLaunchSlots);
-    if (e == hipSuccess) e = hipMalloc((void**)&t->slot_heads, sizeof(uint32_t) * 2 * kLaunchSlots);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&t->slot_heads, sizeof(uint32_t) * kSlotWords * kLaunchSlots);
     if (e == hipSuccess) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) ==
@@ -420,6 +424,7 @@ int vr_set_tuning(const char* key, int value) {
     else if (!strcmp(key, "waves_per_cu")) tn.waves_per_cu = value < 1 ? 1 : (value > 32 ? 32 : value);
     else if (!strcmp(key, "shade_min")) tn.shade_min = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "frame_minor")) tn.frame_minor = value != 0;
+    else if (!strcmp(key, "xcd_queues")) tn.xcd_queues = value != 0;
     else return fail(VR_ERR_INVALID_ARGUMENT, "unknown tuning key '%s'", key);
     return VR_OK;
 }
@@ -523,8 +528,9 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     // launch slot: frame table + queue head in device memory (ring, see VrTreeOpaque)
     const unsigned slot = t->launch_seq.fetch_add(1) % kLaunchSlots;
     k.frames = t->slot_frames + (size_t)slot * vr::kMaxBatch;
-    k.queue_head = t->slot_heads + 2 * slot;
-    k.ray_count_rw = t->slot_heads + 2 * slot + 1;
+    k.queue_head = t->slot_heads + kSlotWords * slot + 16;
+    k.ray_count_rw = t->slot_heads + kSlotWords * slot;
+    k.n_queues = tn.xcd_queues ? 8 : 1;
     k.ray_count = k.ray_count_rw;
     // basis words kept per ray: what the kernel flavour for this basis_dim reads
     const int bd = t->desc.basis_dim;

@@ -78,7 +78,8 @@ struct KParams {
     int64_t n_wave_blocks;       // per frame: n_local_tiles * wblocks_per_tile
     uint32_t total_rays;         // n_frames * n_wave_blocks * 64
     // ---- persistent scheduling ----
-    uint32_t* queue_head;        // device word, reset by prepare_launch_kernel
+    uint32_t* queue_head;        // 8 head words, 16 words apart, reset by prepare_launch_kernel
+    int32_t n_queues;            // 1 or 8 (one ray-id range per XCD)
     const uint32_t* ray_buf;     // compacted rays (written by raygen_kernel), SoA, stride total_rays
     uint32_t* ray_buf_rw;
     const uint32_t* ray_count;   // number of rays in ray_buf

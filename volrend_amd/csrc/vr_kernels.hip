@@ -608,6 +608,7 @@ constexpr int kRing = 128;   // capacity; at most 127 items are ever outstanding
 #ifndef VR_STAGE_RECORDS
 #define VR_STAGE_RECORDS 16
 #endif
+constexpr int kQueueStride = 16;  // words between queue heads (one 64-byte line each)
 constexpr int kHalf = VR_STAGE_RECORDS;  // records staged per pass of the cooperative loader
 
 // Cooperative, line-coalesced record loads: a record of V 16-byte vectors is fetched by a
@@ -795,23 +796,43 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
             // microsecond chip-wide) when the chunk is used up; chunk sizes shrink as the
             // queue drains (guided self-scheduling) so the tail stays balanced.
             if (!exhausted && chunk_next >= chunk_end) {
-                uint32_t base = 0, size = 0;
+                // The ray buffer is cut into n_queues contiguous ranges (= screen regions of
+                // the batch, see locate()), each with its own head word; a wave serves the
+                // range of its XCD first (workgroup b runs on XCD b % 8 -- used for L2
+                // affinity only, never for correctness) and steals from the others when that
+                // range has run dry.
+                uint32_t lo = 0, hi = 0;
                 if (lane == 0) {
-                    const uint32_t seen =
-                        __hip_atomic_load(p.queue_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t remaining = seen < total ? total - seen : 0u;
-                    size = remaining / (2u * gridDim.x);
-                    size = size < 64u ? 64u : (size > 4096u ? 4096u : size);
-                    size &= ~63u;
-                    base = atomicAdd(p.queue_head, size);
+                    const uint32_t nq = (uint32_t)p.n_queues;
+                    const uint32_t mine = blockIdx.x % nq;
+                    const uint32_t waves_per_q = (gridDim.x + nq - 1) / nq;
+                    for (uint32_t a = 0; a < nq; ++a) {
+                        const uint32_t x = (mine + a) % nq;
+                        const uint32_t qlo = (uint32_t)((uint64_t)total * x / nq);
+                        const uint32_t qhi = (uint32_t)((uint64_t)total * (x + 1) / nq);
+                        const uint32_t len = qhi - qlo;
+                        uint32_t* head = p.queue_head + x * kQueueStride;
+                        const uint32_t seen =
+                            __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (seen >= len) continue;
+                        uint32_t size = (len - seen) / (2u * waves_per_q);
+                        size = size < 64u ? 64u : (size > 4096u ? 4096u : size);
+                        size &= ~63u;
+                        const uint32_t base = atomicAdd(head, size);
+                        if (base < len) {
+                            lo = qlo + base;
+                            hi = base + size < len ? qlo + base + size : qhi;
+                            break;
+                        }
+                    }
                 }
-                base = __builtin_amdgcn_readfirstlane(base);
-                size = __builtin_amdgcn_readfirstlane(size);
-                if (base >= total) {
+                lo = __builtin_amdgcn_readfirstlane(lo);
+                hi = __builtin_amdgcn_readfirstlane(hi);
+                if (hi == lo) {
                     exhausted = true;
                 } else {
-                    chunk_next = base;
-                    chunk_end = base + size < total ? base + size : total;
+                    chunk_next = lo;
+                    chunk_end = hi;
                 }
             }
             if (!exhausted) {
@@ -1052,9 +1073,9 @@ __global__ void prepare_launch_kernel(FrameTable tbl, FrameDesc* frames, uint32_
                                       uint32_t* ray_count) {
     const int i = threadIdx.x;
     if (i < tbl.n) frames[tbl.first + i] = tbl.f[i];
-    if (i == 0 && tbl.first == 0) {
-        *queue_head = 0u;
-        *ray_count = 0u;
+    if (tbl.first == 0) {
+        if (i < 8) queue_head[i * kQueueStride] = 0u;
+        if (i == 0) *ray_count = 0u;
     }
 }
 
