@@ -30,7 +30,7 @@ $(PKG)/bin/volrend_headless: $(HOST)/main_headless.cpp $(PKG)/libvolrend_host.a 
 	mkdir -p $(PKG)/bin
 	$(CXX) -O2 -std=c++17 -Iinclude -I$(ROCM)/include -D__HIP_PLATFORM_AMD__ \
 	  $(HOST)/main_headless.cpp $(PKG)/libvolrend_host.a -L$(PKG) -lvolrend_hip \
-	  -L$(ROCM)/lib -lamdhip64 -lz -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,$(ROCM)/lib -o $@
+	  -L$(ROCM)/lib -lamdhip64 -lz -pthread -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,$(ROCM)/lib -o $@
 
 oracle:
 	$(MAKE) -C oracle

@@ -29,7 +29,7 @@ int main(int argc, char* argv[]) {
                 printf("%s kind=%c word=%zu shape=", kv.first.c_str(), kv.second.kind,
                        kv.second.word_size);
                 for (size_t s : kv.second.shape) printf("%zu,", s);
-                printf(" fnv=%llu\n", checksum(kv.second.data_holder.data(), kv.second.num_bytes()));
+                printf(" fnv=%llu\n", checksum(kv.second.bytes(), kv.second.num_bytes()));
             }
         } else if (cmd == "tree" && argc >= 3) {
             N3Tree::upload_on_open = false;
@@ -41,8 +41,8 @@ int main(int argc, char* argv[]) {
             printf("ndc=%d %.9g %.9g %.9g\n", (int)t.use_ndc, t.ndc_width, t.ndc_height,
                    t.ndc_focal);
             printf("child_fnv=%llu data_fnv=%llu extra_bytes=%zu\n",
-                   checksum(t.child_.data_holder.data(), t.child_.num_bytes()),
-                   checksum(t.data_.data_holder.data(), t.data_.num_bytes()),
+                   checksum(t.child_.bytes(), t.child_.num_bytes()),
+                   checksum(t.data_.bytes(), t.data_.num_bytes()),
                    t.extra_.num_bytes());
             if (t.N > 0) {
                 const auto u = t.unpack_index(t.pack_index(3, 1, 0, 1));

@@ -146,3 +146,16 @@ def test_option_parser(exe):
     assert float(kv["sigma"]) == pytest.approx(1e-2) and kv["out"] == "out" and kv["r"] == "1"
     assert kv["gpu"] == "-1"
     assert out[1:] == ["unmatched=pose/0000.txt", "unmatched=pose/0001.txt", "unmatched=--unknown"]
+
+
+def test_large_stored_members_are_viewed_zero_copy(exe, tmp_path):
+    """np.savez (stored, ZIP64 local headers) with MB-sized members: the loader maps the
+    file and hands out views; content must be identical."""
+    t = synth.make_tree(depth=5, basis_dim=9, seed=25)
+    assert t.data.nbytes > (1 << 20)
+    p = str(tmp_path / "big.npz")
+    synth.save_npz(t, p, compressed=False)
+    out = run(exe, "tree", p).splitlines()
+    assert parse_kv(out[0])["capacity"] == str(t.capacity)
+    kv = parse_kv(out[3])
+    assert int(kv["child_fnv"]) == fnv_np(t.child) and int(kv["data_fnv"]) == fnv_np(t.data)

@@ -5,13 +5,20 @@
 // are rendered in batches of --batch frames per launch (default 16).
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <fstream>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <sys/stat.h>
+
+#include <memory>
 
 #include "volrend/internal/imwrite.hpp"
 #include "volrend/internal/opts.hpp"
@@ -73,6 +80,66 @@ void read_intrins(const std::string& path, float& fx, float& fy) {
     ifs >> fx >> g >> g >> g;
     ifs >> g >> fy;
 }
+
+// Frame egress (reference main_headless.cpp:216-222 writes each PNG inline and calls it
+// "a huge bottleneck", README.md:128): PNG encoding runs on worker threads while the GPU
+// renders the next batch; frames come back through pinned, double-buffered host memory.
+class EncodePool {
+   public:
+    explicit EncodePool(unsigned n) {
+        for (unsigned i = 0; i < n; ++i) workers_.emplace_back([this] { run(); });
+    }
+    ~EncodePool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void submit(int group, std::function<void()> fn) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            pending_[group]++;
+            tasks_.push_back({group, std::move(fn)});
+        }
+        cv_.notify_one();
+    }
+    void wait(int group) {  // until every task of this buffer set is done
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_[group] == 0; });
+    }
+
+   private:
+    struct Task {
+        int group;
+        std::function<void()> fn;
+    };
+    void run() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !tasks_.empty(); });
+                if (tasks_.empty()) return;
+                t = std::move(tasks_.front());
+                tasks_.pop_front();
+            }
+            t.fn();
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                pending_[t.group]--;
+            }
+            done_cv_.notify_all();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::deque<Task> tasks_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    int pending_[2] = {0, 0};
+    bool stop_ = false;
+};
 
 void make_dirs(const std::string& path) {
     std::string cur;
@@ -184,10 +251,14 @@ int main(int argc, char* argv[]) {
     const size_t frame_bytes = (size_t)width * height * 4;
     std::vector<void*> images(batch);
     for (int i = 0; i < batch; ++i) HIP_OK(hipMalloc(&images[i], frame_bytes));
-    std::vector<uint8_t> buf;
+    uint8_t* host_sets[2] = {nullptr, nullptr};  // pinned, one per in-flight batch
+    std::unique_ptr<EncodePool> pool;
     if (!out_dir.empty()) {
         make_dirs(out_dir);
-        buf.resize(frame_bytes);
+        for (auto& hs : host_sets) HIP_OK(hipHostMalloc((void**)&hs, frame_bytes * batch));
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = nt == 0 ? 4 : (nt > 16 ? 16 : nt);
+        pool.reset(new EncodePool(nt));
     }
     hipStream_t stream;
     HIP_OK(hipStreamCreate(&stream));
@@ -224,16 +295,31 @@ int main(int argc, char* argv[]) {
             return 1;
         }
         if (!out_dir.empty()) {
+            const int set = (int)((first / batch) & 1);
+            pool->wait(set);  // the encoders are done with this buffer set
             for (int i = 0; i < n; ++i) {
-                if (vr_read_back(buf.data(), images[i], 0, width, height, stream) != VR_OK ||
-                    vr_stream_sync(stream) != VR_OK) {
+                if (vr_read_back(host_sets[set] + frame_bytes * i, images[i], 0, width, height,
+                                 stream) != VR_OK) {
                     fprintf(stderr, "ERROR: %s\n", vr_last_error());
                     return 1;
                 }
+            }
+            if (vr_stream_sync(stream) != VR_OK) {
+                fprintf(stderr, "ERROR: %s\n", vr_last_error());
+                return 1;
+            }
+            for (int i = 0; i < n; ++i) {
                 const std::string fpath = out_dir + "/" + basenames[first + i] + ".png";
-                internal::write_png_file(fpath, buf.data(), width, height);
+                const uint8_t* src = host_sets[set] + frame_bytes * i;
+                pool->submit(set, [fpath, src, width, height] {
+                    internal::write_png_file(fpath, src, width, height);
+                });
             }
         }
+    }
+    if (pool) {
+        pool->wait(0);
+        pool->wait(1);
     }
     HIP_OK(hipEventRecord(stop, stream));
     HIP_OK(hipEventSynchronize(stop));
@@ -245,6 +331,9 @@ int main(int argc, char* argv[]) {
     printf("%.10f fps\n", 1000.f / milliseconds);
     printf("%.4f Mrays/s\n", (double)width * height / (milliseconds * 1e3));
 
+    pool.reset();
+    for (auto& hs : host_sets)
+        if (hs) HIP_OK(hipHostFree(hs));
     for (void* p : images) HIP_OK(hipFree(p));
     HIP_OK(hipStreamDestroy(stream));
     return 0;

@@ -170,7 +170,8 @@ void N3Tree::load_npz(internal::NpzFile& npz) {
         data_.num_vals = n_child * data_dim;
         data_.data_holder.assign(data_.num_vals * 2, 0);
         uint16_t* out = data_.data<uint16_t>();
-        const uint16_t* sigma = need("sigma").data<uint16_t>();
+        const internal::NpyArray& csigma = need("sigma");
+        const uint16_t* sigma = csigma.data<uint16_t>();
         const uint16_t* map = qm.data<uint16_t>();
         const uint16_t* colors = qc.data<uint16_t>();
         for (size_t i = 0; i < n_child; ++i) {
@@ -182,7 +183,8 @@ void N3Tree::load_npz(internal::NpzFile& npz) {
             out[off + data_dim - 1] = sigma[i];
         }
         if (n_ret) {
-            const uint16_t* ret = npz["data_retained"].data<uint16_t>();
+            const internal::NpyArray& cret = npz["data_retained"];
+            const uint16_t* ret = cret.data<uint16_t>();
             for (size_t i = 0; i < n_child; ++i)
                 for (size_t j = 0; j < n_ret; ++j)
                     for (size_t k = 0; k < 3; ++k)
@@ -206,10 +208,14 @@ void N3Tree::load_device() {
     free_device();
     VrTreeDesc d;
     vr_default_tree_desc(&d);
-    d.child = child_.data<int32_t>();
-    d.data = data_.data<uint16_t>();
+    // const access: stored members stay zero-copy views into the mapped file
+    const internal::NpyArray& cchild = child_;
+    const internal::NpyArray& cdata = data_;
+    const internal::NpyArray& cextra = extra_;
+    d.child = cchild.data<int32_t>();
+    d.data = cdata.data<uint16_t>();
     if (!extra_.empty()) {
-        d.extra = extra_.data<float>();
+        d.extra = cextra.data<float>();
         d.extra_count = extra_.num_bytes() / sizeof(float);
     }
     for (int i = 0; i < 3; ++i) {
@@ -241,8 +247,7 @@ bool N3Tree::is_cuda_loaded() { return device_loaded_; }
 
 void N3Tree::clear_cpu_memory() {
     // keep child_ (the reference keeps it for wireframes)
-    data_.data_holder.clear();
-    data_.data_holder.shrink_to_fit();
+    data_.clear();
 }
 
 int N3Tree::pack_index(int nd, int i, int j, int k) { return nd * N3_ + i * N2_ + j * N + k; }

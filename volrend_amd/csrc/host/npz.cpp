@@ -3,6 +3,10 @@
 // headers, both of which numpy's savez produces), inflates deflated members with zlib.
 #include "volrend/internal/npz.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cstdio>
@@ -151,7 +155,8 @@ std::vector<Member> central_directory(const uint8_t* b, size_t size) {
     return out;
 }
 
-NpyArray load_member(const uint8_t* b, size_t size, const Member& m) {
+NpyArray load_member(const uint8_t* b, size_t size, const Member& m,
+                     const std::shared_ptr<void>& mapping) {
     if (m.local_off + 30 > size || rd32(b + m.local_off) != 0x04034b50u)
         fail("bad local header for " + m.name);
     const uint16_t fn = rd16(b + m.local_off + 26), ex = rd16(b + m.local_off + 28);
@@ -162,7 +167,13 @@ NpyArray load_member(const uint8_t* b, size_t size, const Member& m) {
         const size_t pre = parse_npy_preamble(b + data_off, (size_t)m.csize, a);
         const size_t want = a.num_vals * a.word_size;
         if (pre + want > m.csize) fail("member " + m.name + " is truncated");
-        a.data_holder.assign(b + data_off + pre, b + data_off + pre + want);
+        if (mapping && want >= (1u << 16)) {  // big stored member of a mapped file: view it
+            a.view = b + data_off + pre;
+            a.view_bytes = want;
+            a.mapping = mapping;
+        } else {
+            a.data_holder.assign(b + data_off + pre, b + data_off + pre + want);
+        }
     } else if (m.method == 8) {  // deflate: inflate the whole member, then strip the preamble
         std::vector<uint8_t> raw((size_t)m.usize);
         z_stream zs;
@@ -208,7 +219,7 @@ NpyArray load_member(const uint8_t* b, size_t size, const Member& m) {
 
 double NpyArray::as_double(size_t i) const {
     if (i >= num_vals) throw std::out_of_range("npy index");
-    const uint8_t* p = data_holder.data() + i * word_size;
+    const uint8_t* p = bytes() + i * word_size;
     switch (kind) {
         case 'f':
             if (word_size == 4) { float v; std::memcpy(&v, p, 4); return v; }
@@ -235,12 +246,14 @@ double NpyArray::as_double(size_t i) const {
 
 std::string NpyArray::as_string() const {
     std::string s;
+    const uint8_t* d = bytes();
+    const size_t n = num_bytes();
     if (kind == 'U') {  // UCS4 little-endian: keep the low byte of each code point
-        for (size_t i = 0; i + 3 < data_holder.size(); i += 4)
-            if (data_holder[i]) s.push_back((char)data_holder[i]);
+        for (size_t i = 0; i + 3 < n; i += 4)
+            if (d[i]) s.push_back((char)d[i]);
     } else {
-        for (uint8_t c : data_holder)
-            if (c) s.push_back((char)c);
+        for (size_t i = 0; i < n; ++i)
+            if (d[i]) s.push_back((char)d[i]);
     }
     return s;
 }
@@ -259,19 +272,40 @@ NpyArray npy_load(const std::string& path) {
     return npy_parse(buf.data(), buf.size());
 }
 
-NpzFile npz_load_mem(const uint8_t* bytes, size_t size) {
+namespace {
+NpzFile load_all(const uint8_t* bytes, size_t size, const std::shared_ptr<void>& mapping) {
     NpzFile out;
     for (const Member& m : central_directory(bytes, size)) {
         std::string key = m.name;
         if (key.size() > 4 && key.compare(key.size() - 4, 4, ".npy") == 0) key.resize(key.size() - 4);
-        out.emplace(std::move(key), load_member(bytes, size, m));
+        out.emplace(std::move(key), load_member(bytes, size, m, mapping));
     }
     return out;
 }
+}  // namespace
 
+NpzFile npz_load_mem(const uint8_t* bytes, size_t size) { return load_all(bytes, size, nullptr); }
+
+// The file is memory-mapped: stored (np.savez) members become zero-copy views, deflated
+// (np.savez_compressed) members are inflated straight out of the mapping.
 NpzFile npz_load(const std::string& path) {
-    const std::vector<uint8_t> buf = read_file(path);
-    return npz_load_mem(buf.data(), buf.size());
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) fail("cannot open " + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) {
+        ::close(fd);
+        fail("cannot stat " + path);
+    }
+    const size_t size = (size_t)st.st_size;
+    void* addr = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (addr == MAP_FAILED) {  // fall back to reading the file
+        const std::vector<uint8_t> buf = read_file(path);
+        return npz_load_mem(buf.data(), buf.size());
+    }
+    madvise(addr, size, MADV_SEQUENTIAL);
+    std::shared_ptr<void> mapping(addr, [size](void* p) { munmap(p, size); });
+    return load_all(static_cast<const uint8_t*>(addr), size, mapping);
 }
 
 }  // namespace internal
