@@ -191,7 +191,7 @@ int vr_render_batch(vr_tree_t tree, int n_frames, const VrCamera* cams,
 int vr_set_tuning(const char* key, int value);
 /* Scheduling tallies accumulated by instrumented launches (frames with counters):
  * [0] march rounds [1] lanes busy in them [2] shade rounds [3] lanes busy in them
- * [4] cache fills [5] retire rounds [6] rays retired in them [7] scheduler iterations.
+ * [4] distinct leaves summed over shade rounds [5] retire rounds [6] rays retired in them [7] scheduler iterations.
  * Synchronous (copies from the device); reset != 0 clears them. */
 int vr_sched_stats(vr_tree_t tree, uint64_t out[8], int reset);
 /* gathered = world consecutive COMPACT buffers (rank-major), all device memory

@@ -249,7 +249,7 @@ class N3Tree:
         """Scheduling tallies of instrumented launches (see vr_sched_stats)."""
         out = (C.c_uint64 * 8)()
         _abi.check(_abi.lib().vr_sched_stats(self._handle, C.byref(out), 1 if reset else 0))
-        names = ("march_rounds", "march_lanes", "shade_rounds", "shade_lanes", "fills",
+        names = ("march_rounds", "march_lanes", "shade_rounds", "shade_lanes", "distinct_leaves",
                  "retire_rounds", "retired", "iterations")
         return dict(zip(names, [int(v) for v in out]))
 

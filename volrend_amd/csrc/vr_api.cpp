@@ -36,6 +36,7 @@ struct Tuning {
     int shade_min = 48;
     int frame_minor = 1;
     int xcd_queues = 1;
+    int chunk_max = 4096;
 };
 Tuning& tuning() {
     static Tuning tn = [] {
@@ -46,6 +47,7 @@ Tuning& tuning() {
         if (const char* e = getenv("VR_SHADE_MIN")) x.shade_min = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_FRAME_MINOR")) x.frame_minor = atoi(e) != 0;
         if (const char* e = getenv("VR_XCD_QUEUES")) x.xcd_queues = atoi(e) != 0;
+        if (const char* e = getenv("VR_CHUNK_MAX")) x.chunk_max = atoi(e) < 64 ? 64 : (atoi(e) & ~63);
         return x;
     }();
     return tn;
@@ -425,6 +427,7 @@ int vr_set_tuning(const char* key, int value) {
     else if (!strcmp(key, "shade_min")) tn.shade_min = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "frame_minor")) tn.frame_minor = value != 0;
     else if (!strcmp(key, "xcd_queues")) tn.xcd_queues = value != 0;
+    else if (!strcmp(key, "chunk_max")) tn.chunk_max = value < 64 ? 64 : (value & ~63);
     else return fail(VR_ERR_INVALID_ARGUMENT, "unknown tuning key '%s'", key);
     return VR_OK;
 }
@@ -531,6 +534,7 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.queue_head = t->slot_heads + kSlotWords * slot + 16;
     k.ray_count_rw = t->slot_heads + kSlotWords * slot;
     k.n_queues = tn.xcd_queues ? 8 : 1;
+    k.chunk_max = tn.chunk_max;
     k.ray_count = k.ray_count_rw;
     // basis words kept per ray: what the kernel flavour for this basis_dim reads
     const int bd = t->desc.basis_dim;

@@ -80,6 +80,7 @@ struct KParams {
     // ---- persistent scheduling ----
     uint32_t* queue_head;        // 8 head words, 16 words apart, reset by prepare_launch_kernel
     int32_t n_queues;            // 1 or 8 (one ray-id range per XCD)
+    int32_t chunk_max;           // largest ray-id chunk a wave takes at once (multiple of 64)
     const uint32_t* ray_buf;     // compacted rays (written by raygen_kernel), SoA, stride total_rays
     uint32_t* ray_buf_rw;
     const uint32_t* ray_count;   // number of rays in ray_buf

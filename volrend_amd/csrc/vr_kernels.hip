@@ -674,7 +674,7 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
     const uint32_t total = *p.ray_count;  // rays that entered the volume (raygen_kernel)
     const uint32_t cap = p.total_rays;     // field stride of the ray buffer
     // scheduling statistics (instrumented flavours only): rounds and busy lanes per phase
-    uint32_t st_march_r = 0, st_march_l = 0, st_shade_r = 0, st_shade_l = 0, st_fill = 0,
+    uint32_t st_march_r = 0, st_march_l = 0, st_shade_r = 0, st_shade_l = 0, st_distinct = 0,
              st_fin_r = 0, st_fin_l = 0, st_iter = 0;
 
     // Colour evaluation of up to 64 queued items, one per lane, whoever owns them;
@@ -685,6 +685,15 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
         if (COUNT) {
             st_shade_r++;
             st_shade_l += (uint32_t)n;
+            // distinct leaves among the chunk's items (instrumentation only)
+            const uint32_t myleaf =
+                lane < n ? it_leaf[(ring_head + (uint32_t)lane) & (kRing - 1)] : 0xFFFFFFFFu;
+            bool first = lane < n;
+            for (int o = 0; o < kWave; ++o) {
+                const uint32_t other = (uint32_t)__shfl((int)myleaf, o);
+                if (o < lane && other == myleaf) first = false;
+            }
+            st_distinct += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(first));
         }
         Record<BASIS> rec;
         if (Coop<BASIS>::kEnabled) {
@@ -816,7 +825,7 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
                             __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (seen >= len) continue;
                         uint32_t size = (len - seen) / (2u * waves_per_q);
-                        size = size < 64u ? 64u : (size > 4096u ? 4096u : size);
+                        size = size < 64u ? 64u : (size > (uint32_t)p.chunk_max ? (uint32_t)p.chunk_max : size);
                         size &= ~63u;
                         const uint32_t base = atomicAdd(head, size);
                         if (base < len) {
@@ -972,7 +981,7 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
         atomicAdd(&p.sched_stats[1], (unsigned long long)st_march_l);
         atomicAdd(&p.sched_stats[2], (unsigned long long)st_shade_r);
         atomicAdd(&p.sched_stats[3], (unsigned long long)st_shade_l);
-        atomicAdd(&p.sched_stats[4], (unsigned long long)st_fill);
+        atomicAdd(&p.sched_stats[4], (unsigned long long)st_distinct);
         atomicAdd(&p.sched_stats[5], (unsigned long long)st_fin_r);
         atomicAdd(&p.sched_stats[6], (unsigned long long)st_fin_l);
         atomicAdd(&p.sched_stats[7], (unsigned long long)st_iter);
