@@ -179,3 +179,42 @@ def test_access_counters_match_oracle(torch_cuda, fmt, basis_dim):
     assert cnt_g == cnt_o
     assert np.array_equal(img.cpu().numpy(), rgba_o)
     t.free_device()
+
+
+def test_api_errors_are_codes_not_crashes(torch_cuda):
+    """cuda_assert prints and exits (src/cuda/common.cu:8-21); the library returns codes."""
+    torch = torch_cuda
+    import ctypes as C
+    from volrend_amd import _abi, api
+    tree = common.small_scene(depth=3, basis_dim=4, seed=7)
+    t = api.N3Tree.from_synth(tree)
+    img = torch.zeros((32, 32, 4), dtype=torch.uint8, device="cuda")
+    cam = api.Camera(32, 32, 50.0)
+    L = _abi.lib()
+
+    def rc_of(mutate_cam=None, mutate_frame=None, n=1):
+        c = cam.to_c()
+        f = _abi.VrFrame()
+        L.vr_default_frame(C.byref(f))
+        f.rgba = img.data_ptr()
+        if mutate_cam:
+            mutate_cam(c)
+        if mutate_frame:
+            mutate_frame(f)
+        o = api.RenderOptions().to_c()
+        return L.vr_render_batch(t.handle, n, C.byref(c), C.byref(o), C.byref(f), None)
+
+    assert rc_of() == 0
+    assert rc_of(mutate_cam=lambda c: setattr(c, "width", 70000)) == 1
+    assert rc_of(mutate_cam=lambda c: setattr(c, "fx", 0.0)) == 1
+    assert rc_of(mutate_frame=lambda f: setattr(f, "rgba", None)) == 1
+    assert rc_of(mutate_frame=lambda f: setattr(f, "fp_mode", 7)) == 1
+    assert rc_of(mutate_frame=lambda f: (setattr(f, "world", 2), setattr(f, "rank", 2))) == 1
+    assert rc_of(mutate_frame=lambda f: (setattr(f, "tile_w", 12), setattr(f, "tile_h", 8))) == 1
+    assert rc_of(mutate_frame=lambda f: setattr(f, "pitch", 16)) == 1
+    assert rc_of(n=0) == 1 and rc_of(n=1000) == 1
+    assert b"n_frames" in L.vr_last_error()
+    torch.cuda.synchronize()
+    t.free_device()
+    with pytest.raises(RuntimeError):
+        _ = t.handle  # freed trees are not usable

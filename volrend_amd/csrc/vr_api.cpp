@@ -137,6 +137,31 @@ int validate_topology(const int32_t* child, int64_t cap, int N3, char* why, size
     return depth;
 }
 
+// New node numbering: pre-order depth-first from the root (children in slot order),
+// unreachable nodes keep their relative order behind the reachable ones.  "file" keeps
+// the numbering of the file (VR_NODE_ORDER=file, for A/B measurements).
+std::vector<int32_t> node_permutation(const int32_t* child, int64_t cap, int N3) {
+    std::vector<int32_t> perm((size_t)cap, -1);
+    const char* env = getenv("VR_NODE_ORDER");
+    if (env && !strcmp(env, "file")) {
+        for (int64_t i = 0; i < cap; ++i) perm[(size_t)i] = (int32_t)i;
+        return perm;
+    }
+    int32_t next = 0;
+    std::vector<int64_t> stack{0};
+    while (!stack.empty()) {
+        const int64_t n = stack.back();
+        stack.pop_back();
+        perm[(size_t)n] = next++;
+        const int32_t* c = child + n * N3;
+        for (int s = N3 - 1; s >= 0; --s)  // reversed: slot 0 is visited first
+            if (c[s] != 0) stack.push_back(n + c[s]);
+    }
+    for (int64_t i = 0; i < cap; ++i)
+        if (perm[(size_t)i] < 0) perm[(size_t)i] = next++;
+    return perm;
+}
+
 // same rounding sequence as the oracle's norm3 (strict / fma)
 float host_norm3(const float* d, int fma) {
     float s;
@@ -296,9 +321,16 @@ int vr_tree_upload(const VrTreeDesc* d, vr_tree_t* out) {
                 hipSuccess && cus > 0)
             t->n_cus = cus;
     }
+    int32_t* d_perm = nullptr;
+    {
+        const std::vector<int32_t> perm = node_permutation(host_child, d->capacity, N3);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_perm, perm.size() * sizeof(int32_t));
+        if (e == hipSuccess)
+            e = hipMemcpy(d_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess)
-        e = vr::launch_relayout(src_child, src_data, t->nodes, t->leaves, (int64_t)n_slots, N3,
-                                d->data_dim, t->leaf_stride_h, nullptr);
+        e = vr::launch_relayout(src_child, src_data, d_perm, t->nodes, t->leaves, (int64_t)n_slots,
+                                N3, d->data_dim, t->leaf_stride_h, nullptr);
     t->device_bytes = child_sz + leaves_sz + sizeof(uint32_t);
     // restart grid: N == 2 only, node ids must fit the packed entry
     t->grid_levels = 0;
@@ -318,6 +350,7 @@ int vr_tree_upload(const VrTreeDesc* d, vr_tree_t* out) {
         }
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (d_perm) (void)hipFree(d_perm);
     if (d_child) (void)hipFree(d_child);
     if (d_data) (void)hipFree(d_data);
     if (e == hipSuccess && d->extra && d->extra_count) {
@@ -453,6 +486,18 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     const int world = f->world < 1 ? 1 : f->world;
     if (f->rank < 0 || f->rank >= world)
         return fail(VR_ERR_INVALID_ARGUMENT, "rank %d outside world %d", f->rank, world);
+    // pixel coordinates travel as 16+16 bits, pixel offsets as 32 bits
+    if (cam->width < 1 || cam->height < 1 || cam->width > 65535 || cam->height > 65535)
+        return fail(VR_ERR_INVALID_ARGUMENT, "image size %dx%d outside [1, 65535]", cam->width,
+                    cam->height);
+    {
+        const int64_t pitch = f->pitch ? f->pitch : (int64_t)cam->width * 4;
+        if (pitch < (int64_t)cam->width * 4 || pitch * cam->height >= (1ll << 32))
+            return fail(VR_ERR_INVALID_ARGUMENT, "pitch %lld unusable for a %dx%d frame",
+                        (long long)pitch, cam->width, cam->height);
+    }
+    if (!(cam->fx != 0.f) || !(cam->fy != 0.f))
+        return fail(VR_ERR_INVALID_ARGUMENT, "focal length must be non-zero");
 
     bool instrumented = false;
     for (int i = 0; i < n_frames; ++i) {

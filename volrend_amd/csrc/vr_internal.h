@@ -106,9 +106,9 @@ hipError_t launch_probe(const KParams& p, const float probe[3], float* out_dev,
                         hipStream_t stream);
 // upload-time re-layout of the reference arrays into the device layout
 int leaf_stride_halfs(int data_dim);
-hipError_t launch_relayout(const int32_t* child, const uint16_t* data, uint32_t* nodes,
-                           uint16_t* leaves, int64_t n_slots, int N3, int data_dim, int stride_h,
-                           hipStream_t stream);
+hipError_t launch_relayout(const int32_t* child, const uint16_t* data, const int32_t* perm,
+                           uint32_t* nodes, uint16_t* leaves, int64_t n_slots, int N3,
+                           int data_dim, int stride_h, hipStream_t stream);
 hipError_t launch_build_grid(const uint32_t* nodes, uint32_t* grid, int G, hipStream_t stream);
 
 }  // namespace vr

@@ -120,6 +120,10 @@ __device__ __forceinline__ void precalc_basis(const KParams& p, const float* dir
 // Device layout (built once at upload by the relayout kernels below; the
 // tree.npz format and the reference's flat child_/data_ arrays are the INPUT):
 //
+//   Nodes are RENUMBERED depth-first (pre-order) at upload: a subtree is one contiguous
+//   run of the arrays, so the rays of a screen tile -- which walk through one compact
+//   region of space -- touch few cache lines / DRAM pages (the file's numbering is
+//   whatever the exporter produced, typically breadth-first).
 //   nodes[capacity*N3]   one 32-bit word per child slot
 //        bit31 = 0 : internal -- ABSOLUTE index of the child node (> 0)
 //        bit31 = 1 : leaf     -- low 16 bits = sigma as IEEE fp16
@@ -1188,23 +1192,26 @@ __global__ void assemble_kernel(uint8_t* frame, int64_t pitch, const uint8_t* ga
 // ---------------------------------------------------------------------------
 // Upload-time re-layout (reference layout -> device layout, see above)
 // ---------------------------------------------------------------------------
-__global__ void relayout_nodes_kernel(const int32_t* child, const uint16_t* data, uint32_t* nodes,
-                                      int64_t n_slots, int N3, int data_dim) {
+__global__ void relayout_nodes_kernel(const int32_t* child, const uint16_t* data,
+                                      const int32_t* perm, uint32_t* nodes, int64_t n_slots,
+                                      int N3, int data_dim) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
+    const int64_t n = i / N3;
+    const int s = (int)(i - n * N3);
     const int32_t skip = child[i];
     uint32_t w;
     if (skip == 0) {
         w = kLeafBit | (uint32_t)data[i * data_dim + (data_dim - 1)];
     } else {
-        w = (uint32_t)((i / N3) + skip);
+        w = (uint32_t)perm[n + skip];
     }
-    nodes[i] = w;
+    nodes[(int64_t)perm[n] * N3 + s] = w;
 }
 
 // one thread per 16-byte chunk of the padded record array
-__global__ void relayout_leaves_kernel(const uint16_t* data, uint16_t* leaves, int64_t n_slots,
-                                       int data_dim, int stride_h) {
+__global__ void relayout_leaves_kernel(const uint16_t* data, const int32_t* perm, uint16_t* leaves,
+                                       int64_t n_slots, int N3, int data_dim, int stride_h) {
     const int chunks = stride_h / 8;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t slot = gid / chunks;
@@ -1222,7 +1229,9 @@ __global__ void relayout_leaves_kernel(const uint16_t* data, uint16_t* leaves, i
     q.y = h[2] | ((uint32_t)h[3] << 16);
     q.z = h[4] | ((uint32_t)h[5] << 16);
     q.w = h[6] | ((uint32_t)h[7] << 16);
-    reinterpret_cast<uint4*>(leaves + slot * stride_h)[c] = q;
+    const int64_t n = slot / N3;
+    const int64_t dst = (int64_t)perm[n] * N3 + (slot - n * N3);
+    reinterpret_cast<uint4*>(leaves + dst * stride_h)[c] = q;
 }
 
 // grid[cell] = deepest node at level <= G that contains the cell
@@ -1350,15 +1359,15 @@ int leaf_stride_halfs(int data_dim) {
     return stride / 2;
 }
 
-hipError_t launch_relayout(const int32_t* child, const uint16_t* data, uint32_t* nodes,
-                           uint16_t* leaves, int64_t n_slots, int N3, int data_dim, int stride_h,
-                           hipStream_t stream) {
+hipError_t launch_relayout(const int32_t* child, const uint16_t* data, const int32_t* perm,
+                           uint32_t* nodes, uint16_t* leaves, int64_t n_slots, int N3,
+                           int data_dim, int stride_h, hipStream_t stream) {
     const int tpb = 256;
     hipLaunchKernelGGL(relayout_nodes_kernel, dim3((unsigned)((n_slots + tpb - 1) / tpb)), dim3(tpb),
-                       0, stream, child, data, nodes, n_slots, N3, data_dim);
+                       0, stream, child, data, perm, nodes, n_slots, N3, data_dim);
     const int64_t n_chunks = n_slots * (stride_h / 8);
     hipLaunchKernelGGL(relayout_leaves_kernel, dim3((unsigned)((n_chunks + tpb - 1) / tpb)),
-                       dim3(tpb), 0, stream, data, leaves, n_slots, data_dim, stride_h);
+                       dim3(tpb), 0, stream, data, perm, leaves, n_slots, N3, data_dim, stride_h);
     return hipGetLastError();
 }
 
