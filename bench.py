@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64,
                     help="poses per launch (vr_render_batch); steps must be a multiple")
     ap.add_argument("--tune", default="", help="k=v,... scheduling knobs (march_max, refill_min, waves_per_cu)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="launch pipelines (0 = auto: 1 on a single GPU, 2 when tile-sharded so "
+                         "that one launch's ramp-up / tail overlaps its neighbour)")
     ap.add_argument("--readback", action="store_true",
                     help="also copy every frame to pinned host memory inside the timed region "
                          "(the PCIe-inclusive rate; never the headline value)")
@@ -183,6 +186,8 @@ def main():
     frame_sets = [torch.zeros((B, H, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
     frames = [[fs[i] for i in range(B)] for fs in frame_sets]
     sharded = use_dist
+    n_streams = args.streams if args.streams > 0 else (2 if sharded else 1)
+    streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
     nbytes = api.compact_bytes(W, H, shard) if sharded else 0
     # rank 0 receives into ONE [world, B, nbytes] tensor per set (the gather list are its rows),
     # so a single launch de-interleaves a whole batch
@@ -196,7 +201,8 @@ def main():
     pipe = GatherPipeline(
         dist, rank, world,
         lambda: torch.zeros((B, max(nbytes, 1)), dtype=torch.uint8, device=dev),
-        make_gather_list, force_collective=force_gather)
+        make_gather_list, force_collective=force_gather,
+        stream_ctx=lambda j: torch.cuda.stream(streams[j % n_streams]))
 
     def pose_of(step):
         return transforms[step % len(transforms)]
@@ -207,6 +213,7 @@ def main():
         """Launch j renders steps [first_step, first_step+n) in one batch."""
         tr = [pose_of(first_step + i) for i in range(n)]
         ev = timing["events"][j] if timing["events"] else None
+        stream = torch.cuda.current_stream()
         if ev is not None:
             ev[0].record(stream)
         if not sharded:
@@ -226,7 +233,8 @@ def main():
             if host_sets is not None:  # D2H of the batch, async on the render stream
                 host_sets[j % 2][:n].copy_(frame_sets[j % 2][:n], non_blocking=True)
             return  # frames were rendered in place
-        api.assemble_tiles_batch(frame_sets[j % 2], gather_sets[j % 2], n, W, H, shard, stream)
+        api.assemble_tiles_batch(frame_sets[j % 2], gather_sets[j % 2], n, W, H, shard,
+                                 torch.cuda.current_stream())
 
     def run(n_steps, first, events=None):
         timing["events"] = events
@@ -336,6 +344,7 @@ def main():
                 "fp_mode": args.fp,
                 "frames_per_launch": B,
                 "pcie_inclusive": bool(args.readback),
+                "launch_streams": n_streams,
                 "sharded_frame_matches_single_gpu": shard_ok,
                 "parallelism": "single GPU" if world == 1 else
                                f"screen tiles {tile_w}x{tile_h} round-robin over {world} GPUs, "

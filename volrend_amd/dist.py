@@ -5,25 +5,32 @@ box, "gloo" in the CPU tests).  The tree is replicated; every launch renders thi
 interleaved tiles of ``n`` frames into a COMPACT buffer (``VrFrame.layout``), ONE gather
 per launch moves the buffers to rank 0 -- each peer sends its ~1/world share straight to
 the root over its direct xGMI link -- and rank 0 de-interleaves them into frames.
-The gather of launch j overlaps the rendering of launch j+1 (two buffer sets).
+The gather of launch j overlaps the rendering of launch j+1 (two buffer sets); with a
+``stream_ctx`` the launches additionally alternate between streams, so that the ramp-up /
+tail of one launch overlaps its neighbour.
 
 The rendering and the assembly are callbacks, so the same pipeline drives the HIP
 library on GPUs and the CPU oracle in the gloo tests.
 """
 from __future__ import annotations
 
+import contextlib
+
 
 class GatherPipeline:
     def __init__(self, dist, rank: int, world: int, make_buffer, make_gather_list,
-                 force_collective: bool = False):
+                 force_collective: bool = False, stream_ctx=None):
         """``make_buffer()`` -> this rank's compact buffer (tensor) for one launch;
-        ``make_gather_list()`` -> list of ``world`` tensors like it (rank 0 only)."""
+        ``make_gather_list()`` -> list of ``world`` tensors like it (rank 0 only);
+        ``stream_ctx(j)`` -> context manager selecting the stream of launch j (optional;
+        launches j and j+2 share buffers, so use an even number of alternating streams)."""
         self.dist, self.rank, self.world = dist, rank, world
         # world == 1 normally skips the collective; force_collective keeps it (tests the
         # RCCL path on a single-GPU box)
         self.collective = world > 1 or force_collective
         self.bufs = [make_buffer() for _ in range(2)]
         self.gathered = [make_gather_list() if rank == 0 else None for _ in range(2)]
+        self.stream_ctx = stream_ctx or (lambda j: contextlib.nullcontext())
         self.works = {}
         self.sizes = {}
 
@@ -43,20 +50,22 @@ class GatherPipeline:
         Must be called before buffer(j + 2) is written."""
         if j not in self.sizes:
             return
-        n = self.sizes.pop(j)
-        if self.collective:
-            self.works.pop(j).wait()
-        if self.rank == 0:
-            assemble(j, self.gathered[j % 2] if self.collective else [self.bufs[j % 2]], n)
+        with self.stream_ctx(j):
+            n = self.sizes.pop(j)
+            if self.collective:
+                self.works.pop(j).wait()
+            if self.rank == 0:
+                assemble(j, self.gathered[j % 2] if self.collective else [self.bufs[j % 2]], n)
 
     def run(self, n_steps: int, batch: int, render, assemble, first_step: int = 0) -> int:
         """render(j, first_step, n, buffer) enqueues one launch; returns launches done."""
         j, done = 0, 0
         while done < n_steps:
             n = min(batch, n_steps - done)
-            self.retire(j - 2, assemble)
-            render(j, first_step + done, n, self.buffer(j))
-            self.submit(j, n)
+            self.retire(j - 2, assemble)  # same stream as launch j (j - 2 = j mod 2)
+            with self.stream_ctx(j):
+                render(j, first_step + done, n, self.buffer(j))
+                self.submit(j, n)
             done += n
             j += 1
         self.retire(j - 2, assemble)
