@@ -34,3 +34,51 @@ def ulp_diff(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai)
     bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
     return np.abs(ai - bi)
+
+
+def random_tree_general_n(N=4, depth=3, basis_dim=4, fmt="SH", seed=0, p_refine=0.35,
+                          p_occupied=0.5):
+    """A random N^3-tree with arbitrary branching factor (the svox format allows any N;
+    upstream warns 'N != 2 probably doesn't work', our kernels take the literal float
+    descent for it).  Breadth-first numbering, relative child offsets."""
+    from volrend_amd import synth
+    rng = np.random.default_rng(seed)
+    N3 = N ** 3
+    data_dim = 4 if fmt == "RGBA" else 3 * basis_dim + 1
+    levels = [1]
+    child_rows = []
+    n_total = 1
+    for d in range(depth):
+        n = levels[d]
+        if d + 1 < depth:
+            refine = rng.random((n, N3)) < p_refine
+        else:
+            refine = np.zeros((n, N3), dtype=bool)
+        ids = np.zeros((n, N3), dtype=np.int64)
+        k = int(refine.sum())
+        ids[refine] = n_total + np.arange(k)
+        n_total += k
+        child_rows.append(ids)
+        levels.append(k)
+        if k == 0:
+            break
+    cap = n_total
+    child = np.zeros((cap, N3), dtype=np.int32)
+    base = 0
+    for ids in child_rows:
+        n = ids.shape[0]
+        node = (base + np.arange(n))[:, None]
+        child[base:base + n] = np.where(ids != 0, ids - node, 0)
+        base += n
+    data = np.zeros((cap, N3, data_dim), dtype=np.float32)
+    occ = (rng.random((cap, N3)) < p_occupied) & (child == 0)
+    data[..., :-1] = rng.standard_normal((cap, N3, data_dim - 1)) * 0.6
+    if fmt == "RGBA":
+        data[..., :3] = rng.uniform(0.05, 0.95, size=(cap, N3, 3))
+    data[..., -1] = np.where(occ, np.exp(rng.uniform(np.log(2), np.log(60), size=(cap, N3))), 0)
+    data[child != 0] = 0
+    name = "RGBA" if fmt == "RGBA" else f"{fmt}{basis_dim}"
+    return synth.SynthTree(child.reshape(cap, N, N, N),
+                           data.astype(np.float16).reshape(cap, N, N, N, data_dim),
+                           np.full(3, 0.5, np.float32), np.full(3, np.float32(1 / 3), np.float32),
+                           name, None, depth)

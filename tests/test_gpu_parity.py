@@ -218,3 +218,14 @@ def test_api_errors_are_codes_not_crashes(torch_cuda):
     t.free_device()
     with pytest.raises(RuntimeError):
         _ = t.handle  # freed trees are not usable
+
+
+@pytest.mark.parametrize("fp_mode", [0, 1])
+@pytest.mark.parametrize("N,depth,fmt,basis_dim", [(4, 3, "SH", 4), (3, 3, "RGBA", 0), (8, 2, "SH", 9)])
+def test_general_branching_factor_bit_exact(torch_cuda, N, depth, fmt, basis_dim, fp_mode):
+    """N != 2 takes the GENERIC kernel flavour (literal float descent)."""
+    tree = common.random_tree_general_n(N, depth, basis_dim, fmt, seed=500 + N)
+    tr, w, h, f = common.camera_for(pose_idx=3, size=48)
+    rgba_o, acc_o, _ = common.oracle_frame(tree, tr, w, h, f, fp_mode)
+    rgba_g, acc_g = gpu_frame(torch_cuda, tree, tr, w, h, f, fp_mode)
+    assert_parity(rgba_g, acc_g, rgba_o, acc_o)
