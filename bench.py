@@ -41,17 +41,21 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def load_or_make_tree(synth, name: str, local_rank: int, barrier):
-    """Rank-local 0 generates the seeded tree once per node; the others mmap it."""
+def load_or_make_tree(synth, name: str, local_rank: int, barrier, seed=None):
+    """Rank-local 0 generates the seeded tree once per node; the others mmap it.
+    With ``seed`` every rank builds (and caches) its own tree (BASELINE config 4)."""
     os.makedirs(CACHE_DIR, exist_ok=True)
-    cfg = synth.CONFIGS[name]
+    cfg = dict(synth.CONFIGS[name])
+    if seed is not None:
+        cfg["seed"] = seed
+        local_rank = 0
     tag = f"{name}_s{cfg['seed']}_d{cfg['depth']}_b{cfg['basis_dim']}_sh{cfg['shell_leaves']}"
     fchild = os.path.join(CACHE_DIR, tag + "_child.npy")
     fdata = os.path.join(CACHE_DIR, tag + "_data.npy")
     fdone = os.path.join(CACHE_DIR, tag + ".done")
     if local_rank == 0 and not os.path.exists(fdone):
         t0 = time.time()
-        tree = synth.make_config_tree(name)
+        tree = synth.make_config_tree(name, seed=cfg["seed"])
         np.save(fchild, tree.child)
         np.save(fdata, tree.data)
         open(fdone, "w").write("ok")
@@ -112,6 +116,10 @@ def main():
     ap.add_argument("--batch", type=int, default=64,
                     help="poses per launch (vr_render_batch); steps must be a multiple")
     ap.add_argument("--tune", default="", help="k=v,... scheduling knobs (march_max, refill_min, waves_per_cu)")
+    ap.add_argument("--mode", default="tile", choices=["tile", "replicas"],
+                    help="N > 1: 'tile' = every frame sharded by screen tiles + RCCL gather "
+                         "(default, the north-star path); 'replicas' = BASELINE config 4, one "
+                         "tree (seed 1010+rank) and one pose stream per GPU, no communication")
     ap.add_argument("--streams", type=int, default=0,
                     help="launch pipelines (0 = auto: 1 on a single GPU, 2 when tile-sharded so "
                          "that one launch's ramp-up / tail overlaps its neighbour)")
@@ -161,7 +169,9 @@ def main():
 
     cfg = synth.CONFIGS[args.config]
     W, H, focal = cfg["width"], cfg["height"], cfg["focal"]
-    stree = load_or_make_tree(synth, args.config, local_rank, barrier)
+    replicas = args.mode == "replicas" and world > 1
+    stree = load_or_make_tree(synth, args.config, local_rank, barrier,
+                              seed=(1010 + rank) if replicas else None)
     t0 = time.time()
     tree = api.N3Tree.from_synth(stree)
     info = tree.info()
@@ -178,14 +188,15 @@ def main():
         api.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
 
     # per-GPU work per launch shrinks with the tile shard: keep it up with more poses per launch
-    B = max(1, min(args.batch * world, 128))
+    B = max(1, min(args.batch * (1 if args.mode == "replicas" else world), 128))
     tile_h = max(8, (args.tile_rows // 8) * 8)
     tile_w = (W + 7) // 8 * 8
-    shard = api.TileShard(tile_w, tile_h, rank, world, compact=True)
+    sharded = use_dist and not replicas
+    s_rank, s_world = (rank, world) if sharded else (0, 1)
+    shard = api.TileShard(tile_w, tile_h, s_rank, s_world, compact=True)
     # double-buffered outputs: launch j writes set j % 2
     frame_sets = [torch.zeros((B, H, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
     frames = [[fs[i] for i in range(B)] for fs in frame_sets]
-    sharded = use_dist
     n_streams = args.streams if args.streams > 0 else (2 if sharded else 1)
     streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
     nbytes = api.compact_bytes(W, H, shard) if sharded else 0
@@ -198,8 +209,9 @@ def main():
         gather_sets.append(g)
         return [g[r] for r in range(world)]
 
+    # replicas: every rank is its own root and nothing is gathered
     pipe = GatherPipeline(
-        dist, rank, world,
+        dist, rank if sharded else 0, world if sharded else 1,
         lambda: torch.zeros((B, max(nbytes, 1)), dtype=torch.uint8, device=dev),
         make_gather_list, force_collective=force_gather,
         stream_ctx=lambda j: torch.cuda.stream(streams[j % n_streams]))
@@ -249,7 +261,7 @@ def main():
     n_distinct = min(K, len(transforms))
     counters = torch.zeros((B, 7), dtype=torch.int64, device=dev)
     scratch = [torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
-    full = api.TileShard(tile_w, tile_h, rank, world, compact=False)
+    full = api.TileShard(tile_w, tile_h, s_rank, s_world, compact=False)
     jd = 0
     while jd < n_distinct:  # same batching as the timed region
         n = min(B, n_distinct - jd)
@@ -318,7 +330,8 @@ def main():
                            f"+ WRITE_SIZE; FETCH_SIZE under-counts this kernel 2x)")
 
     if rank == 0:
-        rays_total = W * H * K
+        # replicas: every rank rendered its own K frames; tile mode: the K frames were shared
+        rays_total = W * H * K * (world if replicas else 1)
         mrays = rays_total / elapsed / 1e6
         achieved = alg_bytes_per_launch / kern_mean_s / 1e9
         result = {
@@ -326,13 +339,13 @@ def main():
                       f"(synthetic {args.config})",
             "value": round(mrays, 3),
             "unit": "Mrays/s",
-            "fps": round(K / elapsed, 3),
+            "fps": round(K * (world if replicas else 1) / elapsed, 3),
             "n_gpus": world,
             "steps": K,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / K * 1e3, 5),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if replicas else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -346,9 +359,11 @@ def main():
                 "pcie_inclusive": bool(args.readback),
                 "launch_streams": n_streams,
                 "sharded_frame_matches_single_gpu": shard_ok,
-                "parallelism": "single GPU" if world == 1 else
-                               f"screen tiles {tile_w}x{tile_h} round-robin over {world} GPUs, "
-                               f"tree replicated, one RCCL gather of RGBA8 to rank 0 per launch",
+                "parallelism": "single GPU" if world == 1 else (
+                    f"{world} replicas: one tree (seeds 1010..) and pose stream per GPU, no "
+                    f"communication" if replicas else
+                    f"screen tiles {tile_w}x{tile_h} round-robin over {world} GPUs, "
+                    f"tree replicated, one RCCL gather of RGBA8 to rank 0 per launch"),
             },
             "roofline": {
                 "bound": "hbm",

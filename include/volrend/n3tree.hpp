@@ -65,6 +65,12 @@ struct N3Tree {
     // open()/open_mem() upload to the current device unless this is cleared first
     // (host-only tools and tests; the reference always uploads when built with CUDA)
     static bool upload_on_open;
+    // Quantised files (scripts/compress_octree.py): decode the codebooks on the device
+    // during the upload instead of the host loop of src/n3tree.cpp:310-339.  data_ then
+    // stays empty until decode_quantized_host() is called.  Ignored when !upload_on_open.
+    static bool device_decode;
+    // Materialise data_ of a quantised tree on the host (no-op otherwise)
+    void decode_quantized_host();
 
     // Main data holder
     internal::NpyArray data_;
@@ -72,6 +78,8 @@ struct N3Tree {
     internal::NpyArray child_;
     // Optional extra data, only used for SG/ASG
     internal::NpyArray extra_;
+    // Codebook members of a quantised file awaiting the decode (empty otherwise)
+    internal::NpyArray quant_colors_, quant_map_, sigma_, data_retained_;
 
    private:
     void load_npz(internal::NpzFile& npz);

@@ -8,6 +8,8 @@
  * reference tree):
  *
  *   vr_tree_upload / vr_tree_free   N3Tree::load_cuda / free_cuda      src/cuda/n3tree.cu:9-49
+ *   vr_tree_upload_quantized,       the codebook decode loop of
+ *   vr_decode_quantized             N3Tree::load_npz                   src/n3tree.cpp:279-340
  *   VrTreeDesc                      internal::TreeSpec                 include/volrend/internal/data_spec.hpp:23-50
  *   VrCamera                        internal::CameraSpec + the 48-byte
  *                                   Camera::_update upload             data_spec.hpp:11-22, src/camera.cpp:67-75
@@ -84,6 +86,19 @@ typedef struct VrTreeDesc {
     float ndc_focal;
     int32_t memory;          /* 0: pointers are host memory, 1: device memory */
 } VrTreeDesc;
+
+/* Median-cut compressed tree.npz (scripts/compress_octree.py:106-119): instead of
+ * `data`, per basis function a 65536-entry RGB codebook + a 16-bit index per slot,
+ * the densities, and optionally the first basis functions uncompressed.  Pointers
+ * are host or device memory according to VrTreeDesc.memory.  n_slots = capacity*N^3. */
+typedef struct VrQuantDesc {
+    const uint16_t* quant_colors;  /* fp16 [n_quant, 65536, 3] */
+    const uint16_t* quant_map;     /* u16  [n_quant, n_slots] */
+    const uint16_t* sigma;         /* fp16 [n_slots] */
+    const uint16_t* data_retained; /* fp16 [n_retained, n_slots, 3], or NULL */
+    int32_t n_quant;
+    int32_t n_retained;
+} VrQuantDesc;
 
 typedef struct VrTreeInfo {
     int64_t capacity;
@@ -169,6 +184,14 @@ int vr_device_name(int device, char* name, size_t name_len);
 /* ---- tree ------------------------------------------------------------- */
 void vr_default_tree_desc(VrTreeDesc* desc);
 int vr_tree_upload(const VrTreeDesc* desc, vr_tree_t* out);
+/* Same, for a quantised file: desc->data is ignored, the codebooks are decoded on the
+ * device (only ~(2*n_quant + 6*n_retained + 2) instead of 2*data_dim bytes per slot
+ * cross PCIe and no host loop runs).  The resulting tree is identical to uploading
+ * the host-decoded data array. */
+int vr_tree_upload_quantized(const VrTreeDesc* desc, const VrQuantDesc* quant, vr_tree_t* out);
+/* The decode alone: writes the reference's flat data array [n_slots * data_dim] fp16 to
+ * data_out (host or device memory per desc->memory; desc->child/data are not read). */
+int vr_decode_quantized(const VrTreeDesc* desc, const VrQuantDesc* quant, uint16_t* data_out);
 int vr_tree_free(vr_tree_t tree);
 int vr_tree_info(vr_tree_t tree, VrTreeInfo* info);
 

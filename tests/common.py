@@ -82,3 +82,32 @@ def random_tree_general_n(N=4, depth=3, basis_dim=4, fmt="SH", seed=0, p_refine=
                            data.astype(np.float16).reshape(cap, N, N, N, data_dim),
                            np.full(3, 0.5, np.float32), np.full(3, np.float32(1 / 3), np.float32),
                            name, None, depth)
+
+
+def write_quantised_npz(tree, path, n_retain=1, compressed=True):
+    """The compress_octree.py layout (reference scripts/compress_octree.py:106-119) of a
+    synthetic tree: the first ``n_retain`` basis functions uncompressed, one exact
+    codebook (all distinct RGB triples, <= 65536) per remaining basis function."""
+    import numpy as np
+    cap, dd = tree.capacity, tree.data_dim
+    nb = (dd - 1) // 3
+    data = tree.data.reshape(-1, dd)
+    n_slots = data.shape[0]
+    coeff = data[:, :-1].reshape(n_slots, 3, nb)            # [slot, channel, basis]
+    n_q = nb - n_retain
+    qc = np.zeros((n_q, 65536, 3), np.float16)
+    qm = np.zeros((n_q, n_slots), np.uint16)
+    for j in range(n_retain, nb):
+        uniq, inv = np.unique(coeff[:, :, j], axis=0, return_inverse=True)
+        assert len(uniq) <= 65536
+        qc[j - n_retain, :len(uniq)] = uniq
+        qm[j - n_retain] = inv.reshape(-1).astype(np.uint16)
+    N = tree.child.shape[1]
+    arrays = dict(data_dim=np.int64(dd), data_format=np.array(tree.data_format),
+                  child=tree.child, invradius3=tree.invradius3, offset=tree.offset,
+                  quant_colors=qc, quant_map=qm.reshape(n_q, cap, N, N, N),
+                  sigma=data[:, -1].reshape(cap, N, N, N))
+    if n_retain:
+        ret = np.stack([coeff[:, :, j] for j in range(n_retain)])  # [n_ret, slot, 3]
+        arrays["data_retained"] = ret.reshape(n_retain, cap, N, N, N, 3)
+    (np.savez_compressed if compressed else np.savez)(path, **arrays)

@@ -48,7 +48,8 @@ def test_ctypes_prototypes_cover_the_header(lib_path):
 
 
 def test_struct_layouts_match_the_c_compiler():
-    structs = {"VrTreeDesc": _abi.VrTreeDesc, "VrTreeInfo": _abi.VrTreeInfo,
+    structs = {"VrTreeDesc": _abi.VrTreeDesc, "VrQuantDesc": _abi.VrQuantDesc,
+               "VrTreeInfo": _abi.VrTreeInfo,
                "VrCamera": _abi.VrCamera, "VrRenderOptions": _abi.VrRenderOptions,
                "VrFrame": _abi.VrFrame}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "volrend_hip.h"',

@@ -83,3 +83,22 @@ def test_headless_cli_flags(cli, tmp_path):
     # no poses -> the reference's warning and exit code 1
     r = subprocess.run([cli, npz], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "No camera poses specified" in r.stderr
+
+
+def test_headless_cli_quantised_tree(cli, tmp_path):
+    """A compress_octree.py-style file goes through the C++ loader's device decode."""
+    from PIL import Image
+    tree = common.small_scene(depth=4, basis_dim=9, seed=403)
+    npz = str(tmp_path / "q.npz")
+    common.write_quantised_npz(tree, npz, n_retain=1)
+    pose = synth.make_poses(8)[5]
+    paths = synth.write_pose_dir(str(tmp_path), [pose], 64, 90.0)
+    out_dir = str(tmp_path / "o")
+    r = subprocess.run([cli, npz, *paths, "-w", "64", "-h", "64", "--fx", "90", "-o", out_dir],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Decoding quantized colors" in r.stderr + r.stdout
+    img = np.asarray(Image.open(os.path.join(out_dir, "0000.png")))
+    cam = ob.make_camera(synth.c2w_to_transform(pose), 64, 64, 90.0)
+    want, _, _ = ob.render(ob.TreeHandle(tree), cam, ob.default_options(), want_accum=False)
+    assert np.array_equal(img, want)

@@ -229,3 +229,62 @@ def test_general_branching_factor_bit_exact(torch_cuda, N, depth, fmt, basis_dim
     rgba_o, acc_o, _ = common.oracle_frame(tree, tr, w, h, f, fp_mode)
     rgba_g, acc_g = gpu_frame(torch_cuda, tree, tr, w, h, f, fp_mode)
     assert_parity(rgba_g, acc_g, rgba_o, acc_o)
+
+
+@pytest.mark.parametrize("n_retain,basis_dim", [(1, 4), (0, 9), (4, 16)])
+def test_quantised_tree_device_decode(torch_cuda, tmp_path, n_retain, basis_dim):
+    """Quantised tree.npz: the codebook decode runs on the device during the upload
+    (vr_tree_upload_quantized) and must reproduce the reference's host loop
+    (src/n3tree.cpp:310-339) bit for bit -- as a data array and as a rendered frame."""
+    from volrend_amd import api
+    torch = torch_cuda
+    tree = common.small_scene(depth=4, basis_dim=basis_dim, seed=700 + basis_dim)
+    p = str(tmp_path / "q.npz")
+    common.write_quantised_npz(tree, p, n_retain=n_retain, compressed=(n_retain == 1))
+    t = api.N3Tree(p)                       # device decode
+    assert t.data_ is None and t.is_device_loaded()
+    on_dev = t.decode_host(on_device=True)  # vr_decode_quantized
+    assert np.array_equal(on_dev.view(np.uint16), tree.data.view(np.uint16))
+    t2 = api.N3Tree()
+    t2.open(p, upload=True, device_decode=False)  # numpy decode on the host, plain upload
+    assert np.array_equal(t2.data_.view(np.uint16), tree.data.view(np.uint16))
+    tr, w, h, f = common.camera_for(pose_idx=1, size=80)
+    rgba_o, acc_o, cnt = common.oracle_frame(tree, tr, w, h, f, 0)
+    assert cnt["hit_samples"] > 500
+    cam = api.Camera(w, h, f, f)
+    cam.transform = np.asarray(tr, dtype=np.float32)
+    for tt in (t, t2):
+        img = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        api.launch_renderer(tt, cam, api.RenderOptions(), img, None, torch.cuda.current_stream(),
+                            True, accum=acc)
+        torch.cuda.synchronize()
+        assert_parity(img.cpu().numpy(), acc.cpu().numpy(), rgba_o, acc_o)
+
+
+def test_quantised_upload_rejects_bad_descriptors(torch_cuda):
+    import ctypes as C
+    from volrend_amd import _abi
+    L = _abi.lib()
+    tree = common.small_scene(depth=2, basis_dim=4, seed=5)
+    d = _abi.VrTreeDesc()
+    L.vr_default_tree_desc(C.byref(d))
+    child = np.ascontiguousarray(tree.child)
+    d.child, d.N, d.capacity, d.data_dim = child.ctypes.data, 2, tree.capacity, tree.data_dim
+    d.format, d.basis_dim = _abi.FORMAT_SH, 4
+    n_slots = tree.capacity * 8
+    sig = np.zeros(n_slots, np.float16)
+    qm = np.zeros((4, n_slots), np.uint16)
+    qc = np.zeros((4, 65536, 3), np.float16)
+    h = C.c_void_p()
+    q = _abi.VrQuantDesc()
+    q.sigma, q.quant_map, q.quant_colors = sig.ctypes.data, qm.ctypes.data, qc.ctypes.data
+    q.n_quant = 5                                       # 3*5+1 > data_dim
+    assert L.vr_tree_upload_quantized(C.byref(d), C.byref(q), C.byref(h)) == 1
+    q.n_quant, q.n_retained = 3, 1                      # retained without the array
+    assert L.vr_tree_upload_quantized(C.byref(d), C.byref(q), C.byref(h)) == 1
+    q.n_quant, q.n_retained, q.sigma = 4, 0, None
+    assert L.vr_tree_upload_quantized(C.byref(d), C.byref(q), C.byref(h)) == 1
+    q.sigma = sig.ctypes.data
+    assert L.vr_tree_upload_quantized(C.byref(d), C.byref(q), C.byref(h)) == 0
+    L.vr_tree_free(h)

@@ -7,6 +7,8 @@ import subprocess
 import numpy as np
 import pytest
 
+from tests import common
+
 from volrend_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -92,23 +94,8 @@ def test_tree_loader_plain_and_legacy_and_ndc(exe, tmp_path):
 
 def test_tree_loader_quantised(exe, tmp_path):
     t = synth.make_tree(depth=3, basis_dim=4, seed=23)
-    cap, dd, nb = t.capacity, t.data_dim, 4
-    data = t.data.reshape(-1, dd)
-    n_slots = data.shape[0]
-    coeff = data[:, :-1].reshape(n_slots, 3, nb)
-    retained = coeff[:, :, 0][None]
-    qc = np.zeros((nb - 1, 65536, 3), np.float16)
-    qm = np.zeros((nb - 1, n_slots), np.uint16)
-    for j in range(1, nb):
-        uniq, inv = np.unique(coeff[:, :, j], axis=0, return_inverse=True)
-        qc[j - 1, :len(uniq)] = uniq
-        qm[j - 1] = inv.reshape(-1).astype(np.uint16)
     p = str(tmp_path / "q.npz")
-    np.savez_compressed(p, data_dim=np.int64(dd), data_format=np.array("SH4"), child=t.child,
-                        invradius3=t.invradius3, offset=t.offset, quant_colors=qc,
-                        quant_map=qm.reshape(nb - 1, cap, 2, 2, 2),
-                        sigma=data[:, -1].reshape(cap, 2, 2, 2),
-                        data_retained=retained.reshape(1, cap, 2, 2, 2, 3))
+    common.write_quantised_npz(t, p, n_retain=1)
     out = run(exe, "tree", p).splitlines()
     assert int(parse_kv(out[3])["data_fnv"]) == fnv_np(t.data)
 

@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 
+from tests import common
+
 from volrend_amd import api, synth, tiles
 
 
@@ -76,25 +78,8 @@ def test_quantised_tree_decodes_to_the_same_data(tmp_path):
     """compress_octree.py layout (scripts/compress_octree.py:106-119) with --retain 1:
     decode per src/n3tree.cpp:279-340 must reproduce the data array."""
     t = synth.make_tree(depth=3, basis_dim=4, seed=4)
-    cap, dd, nb = t.capacity, t.data_dim, 4
-    data = t.data.reshape(-1, dd)
-    n_slots = data.shape[0]
-    coeff = data[:, :-1].reshape(n_slots, 3, nb)           # [slot, channel, basis]
-    retained = coeff[:, :, 0][None]                         # [1, slot, 3]
-    quant_colors = np.zeros((nb - 1, 65536, 3), np.float16)
-    quant_map = np.zeros((nb - 1, n_slots), np.uint16)
-    for j in range(1, nb):
-        cols = coeff[:, :, j]                               # [slot, 3]
-        uniq, inv = np.unique(cols, axis=0, return_inverse=True)
-        assert len(uniq) <= 65536
-        quant_colors[j - 1, :len(uniq)] = uniq
-        quant_map[j - 1] = inv.reshape(-1).astype(np.uint16)
     p = str(tmp_path / "q.npz")
-    np.savez_compressed(p, data_dim=np.int64(dd), data_format=np.array("SH4"), child=t.child,
-                        invradius3=t.invradius3, offset=t.offset, quant_colors=quant_colors,
-                        quant_map=quant_map.reshape(nb - 1, cap, 2, 2, 2),
-                        sigma=data[:, -1].reshape(cap, 2, 2, 2),
-                        data_retained=retained.reshape(1, cap, 2, 2, 2, 3))
+    common.write_quantised_npz(t, p, n_retain=1)
     n = api.N3Tree()
     n.open(p, upload=False)
     assert np.array_equal(n.data_.view(np.uint16), t.data.view(np.uint16))

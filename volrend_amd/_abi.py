@@ -28,6 +28,11 @@ class VrTreeDesc(C.Structure):
                 ("ndc_height", C.c_float), ("ndc_focal", C.c_float), ("memory", C.c_int32)]
 
 
+class VrQuantDesc(C.Structure):
+    _fields_ = [("quant_colors", C.c_void_p), ("quant_map", C.c_void_p), ("sigma", C.c_void_p),
+                ("data_retained", C.c_void_p), ("n_quant", C.c_int32), ("n_retained", C.c_int32)]
+
+
 class VrTreeInfo(C.Structure):
     _fields_ = [("capacity", C.c_int64), ("N", C.c_int32), ("data_dim", C.c_int32),
                 ("format", C.c_int32), ("basis_dim", C.c_int32), ("max_depth", C.c_int32),
@@ -69,6 +74,9 @@ PROTOTYPES = {
     "vr_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "vr_default_tree_desc": (None, [C.POINTER(VrTreeDesc)]),
     "vr_tree_upload": (C.c_int, [C.POINTER(VrTreeDesc), C.POINTER(C.c_void_p)]),
+    "vr_tree_upload_quantized": (C.c_int, [C.POINTER(VrTreeDesc), C.POINTER(VrQuantDesc),
+                                           C.POINTER(C.c_void_p)]),
+    "vr_decode_quantized": (C.c_int, [C.POINTER(VrTreeDesc), C.POINTER(VrQuantDesc), C.c_void_p]),
     "vr_tree_free": (C.c_int, [C.c_void_p]),
     "vr_tree_info": (C.c_int, [C.c_void_p, C.POINTER(VrTreeInfo)]),
     "vr_default_options": (None, [C.POINTER(VrRenderOptions)]),

@@ -129,6 +129,7 @@ class N3Tree:
         self.child_ = None
         self.data_ = None
         self.extra_ = None
+        self.quant_ = None  # codebook arrays of a quantised file awaiting the device decode
         self._handle = C.c_void_p()
         self._loaded = False
         if path is not None:
@@ -152,24 +153,31 @@ class N3Tree:
         return cls.from_arrays(tree.child, tree.data, tree.offset, tree.invradius3,
                                tree.data_format, tree.extra, ndc=ndc, upload=upload)
 
-    def _set_arrays(self, child, data, offset, invradius3, data_format, extra):
+    def _set_arrays(self, child, data, offset, invradius3, data_format, extra, data_dim=None):
         child = np.ascontiguousarray(child, dtype=np.int32)
         self.N = int(child.shape[1])
         self.capacity = int(child.shape[0])
         self.child_ = child.reshape(self.capacity, self.N, self.N, self.N)
-        data = np.asarray(data)
-        if data.dtype != np.float16:
-            raise RuntimeError("data must be stored in half precision")  # n3tree.cpp:344-346
-        self.data_ = np.ascontiguousarray(data)
-        self.data_dim = int(self.data_.shape[-1])
+        self.quant_ = None
+        if data is None:  # quantised file, decoded on the device at upload
+            self.data_ = None
+            self.data_dim = int(data_dim)
+        else:
+            data = np.asarray(data)
+            if data.dtype != np.float16:
+                raise RuntimeError("data must be stored in half precision")  # n3tree.cpp:344-346
+            self.data_ = np.ascontiguousarray(data)
+            self.data_dim = int(self.data_.shape[-1])
         self.data_format = parse_data_format(data_format)
         self.scale = np.asarray(invradius3, dtype=np.float32).reshape(3).copy()
         self.offset = np.asarray(offset, dtype=np.float32).reshape(3).copy()
         self.extra_ = None if extra is None else np.ascontiguousarray(extra, dtype=np.float32)
 
-    def open(self, path: str, upload: bool = True) -> None:
+    def open(self, path: str, upload: bool = True, device_decode: bool = True) -> None:
         """``N3Tree::open`` + ``load_npz`` (src/n3tree.cpp:111-154, 228-362).
-        ``upload=False`` stops before ``load_cuda`` (host-only use, e.g. format tests)."""
+        ``upload=False`` stops before ``load_cuda`` (host-only use, e.g. format tests).
+        A quantised file is decoded on the device during the upload (``data_`` stays None
+        until ``decode_host()``) unless ``device_decode=False`` or ``upload=False``."""
         if not path.endswith(".npz"):
             raise ValueError("tree file must end in .npz")  # assert at n3tree.cpp:119
         if not os.path.exists(path):
@@ -185,14 +193,18 @@ class N3Tree:
         else:
             scale = np.full(3, float(z["invradius"]), dtype=np.float32)
         child = z["child"]
-        if "quant_colors" in z.files:
-            data = _decode_quantised(z, child, data_dim)
-        else:
-            data = z["data"]
         extra = z["extra_data"] if "extra_data" in z.files else None
-        self._set_arrays(child, data, z["offset"], scale, fmt, extra)
-        if self.data_dim != data_dim:
-            raise RuntimeError("data_dim does not match the data array")
+        if "quant_colors" in z.files and upload and device_decode:
+            self._set_arrays(child, None, z["offset"], scale, fmt, extra, data_dim=data_dim)
+            self.quant_ = _quant_arrays(z, child)
+        else:
+            if "quant_colors" in z.files:
+                data = _decode_quantised(z, child, data_dim)
+            else:
+                data = z["data"]
+            self._set_arrays(child, data, z["offset"], scale, fmt, extra)
+            if self.data_dim != data_dim:
+                raise RuntimeError("data_dim does not match the data array")
         # LLFF NDC sidecar, n3tree.cpp:121,131-148
         pb = path[:-4] + "_poses_bounds.npy"
         if os.path.exists(pb):
@@ -211,7 +223,10 @@ class N3Tree:
         d = _abi.VrTreeDesc()
         L.vr_default_tree_desc(C.byref(d))
         d.child = self.child_.ctypes.data
-        d.data = self.data_.ctypes.data
+        if self.data_ is not None:
+            d.data = self.data_.ctypes.data
+        elif self.quant_ is None:
+            raise RuntimeError("tree has no data (clear_cpu_memory was called)")
         if self.extra_ is not None:
             d.extra = self.extra_.ctypes.data
             d.extra_count = self.extra_.size
@@ -228,9 +243,44 @@ class N3Tree:
         d.ndc_focal = self.ndc_focal
         d.memory = 0
         h = C.c_void_p()
-        _abi.check(L.vr_tree_upload(C.byref(d), C.byref(h)))
+        if self.data_ is None:
+            _abi.check(L.vr_tree_upload_quantized(C.byref(d), C.byref(self._quant_desc()),
+                                                  C.byref(h)))
+        else:
+            _abi.check(L.vr_tree_upload(C.byref(d), C.byref(h)))
         self._handle = h
         self._loaded = True
+
+    def _quant_desc(self) -> "_abi.VrQuantDesc":
+        q = _abi.VrQuantDesc()
+        a = self.quant_
+        q.n_quant = a["quant_map"].shape[0]
+        q.quant_colors = a["quant_colors"].ctypes.data
+        q.quant_map = a["quant_map"].ctypes.data
+        q.sigma = a["sigma"].ctypes.data
+        if a["data_retained"] is not None:
+            q.n_retained = a["data_retained"].shape[0]
+            q.data_retained = a["data_retained"].ctypes.data
+        return q
+
+    def decode_host(self, on_device: bool = False) -> np.ndarray:
+        """Materialises ``data_`` of a quantised tree: numpy restatement of the reference loop
+        (src/n3tree.cpp:310-339), or the library's device decode copied back."""
+        if self.data_ is None and self.quant_ is not None:
+            shape = (self.capacity, self.N, self.N, self.N, self.data_dim)
+            if on_device:
+                d = _abi.VrTreeDesc()
+                _abi.lib().vr_default_tree_desc(C.byref(d))
+                d.N, d.capacity, d.data_dim, d.memory = self.N, self.capacity, self.data_dim, 0
+                out = np.empty(shape, np.float16)
+                _abi.check(_abi.lib().vr_decode_quantized(C.byref(d), C.byref(self._quant_desc()),
+                                                          out.ctypes.data))
+                self.data_ = out
+            else:
+                a = self.quant_
+                self.data_ = _decode_arrays(a["quant_colors"], a["quant_map"], a["sigma"],
+                                            a["data_retained"], self.data_dim).reshape(shape)
+        return self.data_
 
     def free_device(self) -> None:
         if self._handle:
@@ -244,6 +294,7 @@ class N3Tree:
     def clear_cpu_memory(self) -> None:
         """n3tree.cpp:441-447: keeps ``child_`` (wireframes), drops ``data_``."""
         self.data_ = None
+        self.quant_ = None
 
     def sched_stats(self, reset: bool = True) -> dict:
         """Scheduling tallies of instrumented launches (see vr_sched_stats)."""
@@ -271,13 +322,9 @@ class N3Tree:
             pass
 
 
-def _decode_quantised(z, child, data_dim: int) -> np.ndarray:
-    """Median-cut codebook decode, src/n3tree.cpp:279-340.
-
-    data[slot, j + n_retain + c*n_basis] = quant_colors[j, quant_map[j, slot], c]
-    data[slot, j + c*n_basis]            = data_retained[j, slot, c]
-    data[slot, data_dim-1]               = sigma[slot]
-    """
+def _quant_arrays(z, child) -> dict:
+    """The codebook members of a quantised tree.npz (scripts/compress_octree.py:106-119),
+    checked as src/n3tree.cpp:279-293 does and flattened to [.., n_slots, ..]."""
     qc = z["quant_colors"]
     if qc.dtype != np.float16:
         raise RuntimeError("codebook must be stored in half precision")
@@ -286,23 +333,43 @@ def _decode_quantised(z, child, data_dim: int) -> np.ndarray:
     if qc.shape[0] != n_q:
         raise RuntimeError("codebook and map basis numbers does not match")
     cap, N = qm.shape[1], child.shape[1]
+    n_slots = cap * N * N * N
     retained = z["data_retained"] if "data_retained" in z.files else None
+    return dict(
+        quant_colors=np.ascontiguousarray(qc),
+        quant_map=np.ascontiguousarray(qm.reshape(n_q, n_slots), dtype=np.uint16),
+        sigma=np.ascontiguousarray(z["sigma"].reshape(n_slots), dtype=np.float16),
+        data_retained=None if retained is None else np.ascontiguousarray(
+            retained.reshape(retained.shape[0], n_slots, 3), dtype=np.float16))
+
+
+def _decode_arrays(qc, qm, sigma, retained, data_dim: int) -> np.ndarray:
+    """Median-cut codebook decode, src/n3tree.cpp:279-340.
+
+    data[slot, j + n_retain + c*n_basis] = quant_colors[j, quant_map[j, slot], c]
+    data[slot, j + c*n_basis]            = data_retained[j, slot, c]
+    data[slot, data_dim-1]               = sigma[slot]
+    """
+    n_q, n_slots = qm.shape
     n_ret = 0 if retained is None else retained.shape[0]
     n_basis = n_q + n_ret
-    n_slots = cap * N * N * N
     data = np.zeros((n_slots, data_dim), dtype=np.float16)
-    qm2 = qm.reshape(n_q, n_slots)
     for j in range(n_q):
-        cols = qc[j][qm2[j].astype(np.int64)]  # [n_slots, 3]
+        cols = qc[j][qm[j].astype(np.int64)]  # [n_slots, 3]
         for c in range(3):
             data[:, j + n_ret + c * n_basis] = cols[:, c]
-    data[:, data_dim - 1] = z["sigma"].reshape(n_slots)
-    if n_ret:
-        r = retained.reshape(n_ret, n_slots, 3)
-        for j in range(n_ret):
-            for c in range(3):
-                data[:, j + c * n_basis] = r[j, :, c]
-    return data.reshape(cap, N, N, N, data_dim)
+    data[:, data_dim - 1] = sigma
+    for j in range(n_ret):
+        for c in range(3):
+            data[:, j + c * n_basis] = retained[j, :, c]
+    return data
+
+
+def _decode_quantised(z, child, data_dim: int) -> np.ndarray:
+    a = _quant_arrays(z, child)
+    cap, N = child.shape[0], child.shape[1]
+    return _decode_arrays(a["quant_colors"], a["quant_map"], a["sigma"], a["data_retained"],
+                          data_dim).reshape(cap, N, N, N, data_dim)
 
 
 def _ptr(x) -> int | None:

@@ -68,6 +68,7 @@ void unpack_llff_poses_bounds(const internal::NpyArray& pb, float& width, float&
 }  // namespace
 
 bool N3Tree::upload_on_open = true;
+bool N3Tree::device_decode = true;
 
 N3Tree::N3Tree() {}
 N3Tree::N3Tree(const std::string& path) { open(path); }
@@ -160,36 +161,20 @@ void N3Tree::load_npz(internal::NpzFile& npz) {
         capacity = (int)qm.shape[1];
         const size_t n_q = qm.shape[0];
         if (qc.shape[0] != n_q) throw std::runtime_error("codebook and map basis numbers does not match");
-        const size_t n_ret = npz.count("data_retained") ? npz["data_retained"].shape[0] : 0;
-        const size_t n_basis = n_q + n_ret;
-        const size_t n_child = (size_t)capacity * N3_;
+        if ((int)qm.shape.size() != 5 || qc.shape.size() != 3 || qc.shape[1] != 65536 ||
+            qc.shape[2] != 3)
+            throw std::runtime_error("quant_map / quant_colors have unexpected shapes");
+        need("sigma");
+        quant_colors_ = std::move(npz["quant_colors"]);
+        quant_map_ = std::move(npz["quant_map"]);
+        sigma_ = std::move(npz["sigma"]);
+        data_retained_ = npz.count("data_retained") ? std::move(npz["data_retained"])
+                                                    : internal::NpyArray();
+        if (sigma_.word_size != 2 || quant_map_.word_size != 2 ||
+            (!data_retained_.empty() && data_retained_.word_size != 2))
+            throw std::runtime_error("quantised arrays must be 16-bit");
         data_ = internal::NpyArray();
-        data_.shape = {(size_t)capacity, (size_t)N, (size_t)N, (size_t)N, (size_t)data_dim};
-        data_.word_size = 2;
-        data_.kind = 'f';
-        data_.num_vals = n_child * data_dim;
-        data_.data_holder.assign(data_.num_vals * 2, 0);
-        uint16_t* out = data_.data<uint16_t>();
-        const internal::NpyArray& csigma = need("sigma");
-        const uint16_t* sigma = csigma.data<uint16_t>();
-        const uint16_t* map = qm.data<uint16_t>();
-        const uint16_t* colors = qc.data<uint16_t>();
-        for (size_t i = 0; i < n_child; ++i) {
-            const size_t off = i * data_dim;
-            for (size_t j = 0; j < n_q; ++j) {
-                const uint16_t* c = colors + (j * 65536 + map[j * n_child + i]) * 3;
-                for (size_t k = 0; k < 3; ++k) out[off + j + n_ret + k * n_basis] = c[k];
-            }
-            out[off + data_dim - 1] = sigma[i];
-        }
-        if (n_ret) {
-            const internal::NpyArray& cret = npz["data_retained"];
-            const uint16_t* ret = cret.data<uint16_t>();
-            for (size_t i = 0; i < n_child; ++i)
-                for (size_t j = 0; j < n_ret; ++j)
-                    for (size_t k = 0; k < 3; ++k)
-                        out[i * data_dim + j + k * n_basis] = ret[(j * n_child + i) * 3 + k];
-        }
+        if (!(device_decode && upload_on_open)) decode_quantized_host();
     } else {
         internal::NpyArray& d = need("data");
         capacity = (int)d.shape[0];
@@ -204,6 +189,43 @@ void N3Tree::load_npz(internal::NpzFile& npz) {
         extra_ = internal::NpyArray();
 }
 
+void N3Tree::decode_quantized_host() {
+    // reference src/n3tree.cpp:296-340
+    if (quant_map_.empty() || !data_.empty()) return;
+    const size_t n_q = quant_map_.shape[0];
+    const size_t n_ret = data_retained_.empty() ? 0 : data_retained_.shape[0];
+    const size_t n_basis = n_q + n_ret;
+    const size_t n_child = (size_t)capacity * N3_;
+    if (3 * n_basis + 1 > (size_t)data_dim)
+        throw std::runtime_error("quantised basis functions do not fit data_dim");
+    data_.shape = {(size_t)capacity, (size_t)N, (size_t)N, (size_t)N, (size_t)data_dim};
+    data_.word_size = 2;
+    data_.kind = 'f';
+    data_.num_vals = n_child * data_dim;
+    data_.data_holder.assign(data_.num_vals * 2, 0);
+    uint16_t* out = data_.data<uint16_t>();
+    const internal::NpyArray &cs = sigma_, &cm = quant_map_, &cc = quant_colors_,
+                             &cr = data_retained_;
+    const uint16_t* sigma = cs.data<uint16_t>();
+    const uint16_t* map = cm.data<uint16_t>();
+    const uint16_t* colors = cc.data<uint16_t>();
+    for (size_t i = 0; i < n_child; ++i) {
+        const size_t off = i * data_dim;
+        for (size_t j = 0; j < n_q; ++j) {
+            const uint16_t* c = colors + (j * 65536 + map[j * n_child + i]) * 3;
+            for (size_t k = 0; k < 3; ++k) out[off + j + n_ret + k * n_basis] = c[k];
+        }
+        out[off + data_dim - 1] = sigma[i];
+    }
+    if (n_ret) {
+        const uint16_t* ret = cr.data<uint16_t>();
+        for (size_t i = 0; i < n_child; ++i)
+            for (size_t j = 0; j < n_ret; ++j)
+                for (size_t k = 0; k < 3; ++k)
+                    out[i * data_dim + j + k * n_basis] = ret[(j * n_child + i) * 3 + k];
+    }
+}
+
 void N3Tree::load_device() {
     free_device();
     VrTreeDesc d;
@@ -213,7 +235,8 @@ void N3Tree::load_device() {
     const internal::NpyArray& cdata = data_;
     const internal::NpyArray& cextra = extra_;
     d.child = cchild.data<int32_t>();
-    d.data = cdata.data<uint16_t>();
+    const bool quantised = data_.empty() && !quant_map_.empty();
+    if (!quantised) d.data = cdata.data<uint16_t>();
     if (!extra_.empty()) {
         d.extra = cextra.data<float>();
         d.extra_count = extra_.num_bytes() / sizeof(float);
@@ -231,7 +254,22 @@ void N3Tree::load_device() {
     d.ndc_height = ndc_height;
     d.ndc_focal = ndc_focal;
     d.memory = 0;
-    if (vr_tree_upload(&d, &device) != VR_OK)
+    int rc;
+    if (quantised) {
+        const internal::NpyArray &cs = sigma_, &cm = quant_map_, &cc = quant_colors_,
+                                 &cr = data_retained_;
+        VrQuantDesc q;
+        q.quant_colors = cc.data<uint16_t>();
+        q.quant_map = cm.data<uint16_t>();
+        q.sigma = cs.data<uint16_t>();
+        q.data_retained = cr.empty() ? nullptr : cr.data<uint16_t>();
+        q.n_quant = (int)cm.shape[0];
+        q.n_retained = cr.empty() ? 0 : (int)cr.shape[0];
+        rc = vr_tree_upload_quantized(&d, &q, &device);
+    } else {
+        rc = vr_tree_upload(&d, &device);
+    }
+    if (rc != VR_OK)
         throw std::runtime_error(std::string("vr_tree_upload: ") + vr_last_error());
     device_loaded_ = true;
 }
@@ -248,6 +286,10 @@ bool N3Tree::is_cuda_loaded() { return device_loaded_; }
 void N3Tree::clear_cpu_memory() {
     // keep child_ (the reference keeps it for wireframes)
     data_.clear();
+    quant_colors_.clear();
+    quant_map_.clear();
+    sigma_.clear();
+    data_retained_.clear();
 }
 
 int N3Tree::pack_index(int nd, int i, int j, int k) { return nd * N3_ + i * N2_ + j * N + k; }

@@ -11,6 +11,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <fstream>
 
 namespace volrend {
@@ -274,12 +275,34 @@ NpyArray npy_load(const std::string& path) {
 
 namespace {
 NpzFile load_all(const uint8_t* bytes, size_t size, const std::shared_ptr<void>& mapping) {
+    // A deflate stream is sequential, but the members are independent: the big ones
+    // (child, data / quant_map, sigma, ...) inflate concurrently, one thread each.
     NpzFile out;
-    for (const Member& m : central_directory(bytes, size)) {
+    const std::vector<Member> members = central_directory(bytes, size);
+    auto key_of = [](const Member& m) {
         std::string key = m.name;
         if (key.size() > 4 && key.compare(key.size() - 4, 4, ".npy") == 0) key.resize(key.size() - 4);
-        out.emplace(std::move(key), load_member(bytes, size, m, mapping));
+        return key;
+    };
+    std::vector<std::pair<size_t, std::future<NpyArray>>> pending;
+    for (size_t i = 0; i < members.size(); ++i) {
+        const Member& m = members[i];
+        if (m.method == 8 && m.csize >= (1u << 20))
+            pending.emplace_back(i, std::async(std::launch::async, [&, i] {
+                                     return load_member(bytes, size, members[i], mapping);
+                                 }));
+        else
+            out.emplace(key_of(m), load_member(bytes, size, m, mapping));
     }
+    std::exception_ptr err;
+    for (auto& p : pending) {  // join everything before rethrowing
+        try {
+            out.emplace(key_of(members[p.first]), p.second.get());
+        } catch (...) {
+            if (!err) err = std::current_exception();
+        }
+    }
+    if (err) std::rethrow_exception(err);
     return out;
 }
 }  // namespace

@@ -243,10 +243,58 @@ void vr_default_tree_desc(VrTreeDesc* d) {
     d->ndc_width = -1.f;
 }
 
-int vr_tree_upload(const VrTreeDesc* d, vr_tree_t* out) {
-    if (!d || !out) return fail(VR_ERR_INVALID_ARGUMENT, "desc/out is NULL");
-    *out = nullptr;
-    if (!d->child || !d->data) return fail(VR_ERR_INVALID_ARGUMENT, "child/data is NULL");
+// Validates the codebook arrays of a quantised tree against the tree description.
+static int check_quant(const VrTreeDesc* d, const VrQuantDesc* q) {
+    if (q->n_quant < 0 || q->n_retained < 0 || q->n_quant + q->n_retained < 1)
+        return fail(VR_ERR_INVALID_ARGUMENT, "quantised tree needs at least one basis function");
+    if (3 * (q->n_quant + q->n_retained) + 1 > d->data_dim)
+        return fail(VR_ERR_INVALID_ARGUMENT, "%d quantised + %d retained basis functions do not "
+                    "fit data_dim=%d", q->n_quant, q->n_retained, d->data_dim);
+    if (!q->sigma) return fail(VR_ERR_INVALID_ARGUMENT, "sigma is NULL");
+    if (q->n_quant && (!q->quant_colors || !q->quant_map))
+        return fail(VR_ERR_INVALID_ARGUMENT, "quant_colors/quant_map is NULL");
+    if (q->n_retained && !q->data_retained)
+        return fail(VR_ERR_INVALID_ARGUMENT, "data_retained is NULL");
+    return VR_OK;
+}
+
+// Stages the codebook arrays on the device (unless they are there already) and decodes
+// them into `d_data` (flat reference layout, n_slots * data_dim halfs, device memory).
+static hipError_t decode_quant_on_device(const VrTreeDesc* d, const VrQuantDesc* q, size_t n_slots,
+                                         uint16_t* d_data) {
+    const size_t sz_colors = (size_t)q->n_quant * 65536 * 3 * sizeof(uint16_t);
+    const size_t sz_map = (size_t)q->n_quant * n_slots * sizeof(uint16_t);
+    const size_t sz_sigma = n_slots * sizeof(uint16_t);
+    const size_t sz_ret = (size_t)q->n_retained * n_slots * 3 * sizeof(uint16_t);
+    const void* src[4] = {q->quant_colors, q->quant_map, q->sigma, q->data_retained};
+    const size_t sz[4] = {sz_colors, sz_map, sz_sigma, sz_ret};
+    void* tmp[4] = {nullptr, nullptr, nullptr, nullptr};
+    const void* dev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) {
+        if (!sz[i]) continue;
+        if (d->memory == 1) {
+            dev[i] = src[i];
+            continue;
+        }
+        e = hipMalloc(&tmp[i], sz[i]);
+        if (e == hipSuccess) e = hipMemcpy(tmp[i], src[i], sz[i], hipMemcpyHostToDevice);
+        dev[i] = tmp[i];
+    }
+    if (e == hipSuccess)
+        e = vr::launch_decode_quant((const uint16_t*)dev[0], (const uint16_t*)dev[1],
+                                    (const uint16_t*)dev[2], (const uint16_t*)dev[3], d_data,
+                                    (int64_t)n_slots, q->n_quant, q->n_retained, d->data_dim,
+                                    nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    for (int i = 0; i < 4; ++i)
+        if (tmp[i]) (void)hipFree(tmp[i]);
+    return e;
+}
+
+static int check_tree_desc(const VrTreeDesc* d, bool need_data) {
+    if (!d->child || (need_data && !d->data))
+        return fail(VR_ERR_INVALID_ARGUMENT, "child/data is NULL");
     if (d->N < 2 || d->N > 16) return fail(VR_ERR_INVALID_ARGUMENT, "N=%d out of range", d->N);
     if (d->capacity <= 0) return fail(VR_ERR_INVALID_ARGUMENT, "capacity must be positive");
     if (d->format < VR_FORMAT_RGBA || d->format > VR_FORMAT_ASG)
@@ -262,6 +310,15 @@ int vr_tree_upload(const VrTreeDesc* d, vr_tree_t* out) {
         return fail(VR_ERR_INVALID_ARGUMENT, "SG needs basis_dim*4 extra floats");
     if (d->format == VR_FORMAT_ASG && (!d->extra || d->extra_count < (uint64_t)d->basis_dim * 11))
         return fail(VR_ERR_INVALID_ARGUMENT, "ASG needs basis_dim*11 extra floats");
+    return VR_OK;
+}
+
+static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out) {
+    if (!d || !out) return fail(VR_ERR_INVALID_ARGUMENT, "desc/out is NULL");
+    *out = nullptr;
+    if (int rc = check_tree_desc(d, q == nullptr)) return rc;
+    if (q)
+        if (int rc = check_quant(d, q)) return rc;
 
     const int N3 = d->N * d->N * d->N;
     const size_t n_slots = (size_t)d->capacity * N3;
@@ -296,10 +353,16 @@ int vr_tree_upload(const VrTreeDesc* d, vr_tree_t* out) {
     const uint16_t* src_data = d->data;
     if (d->memory != 1) {
         if (e == hipSuccess) e = hipMalloc((void**)&d_child, child_sz);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_data, data_sz);
         if (e == hipSuccess) e = hipMemcpy(d_child, d->child, child_sz, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_data, d->data, data_sz, hipMemcpyHostToDevice);
         src_child = d_child;
+    }
+    if (q) {  // quantised file: only the codebook arrays cross PCIe, the decode runs here
+        if (e == hipSuccess) e = hipMalloc((void**)&d_data, data_sz);
+        if (e == hipSuccess) e = decode_quant_on_device(d, q, n_slots, d_data);
+        src_data = d_data;
+    } else if (d->memory != 1) {
+        if (e == hipSuccess) e = hipMalloc((void**)&d_data, data_sz);
+        if (e == hipSuccess) e = hipMemcpy(d_data, d->data, data_sz, hipMemcpyHostToDevice);
         src_data = d_data;
     }
     t->leaf_stride_h = vr::leaf_stride_halfs(d->data_dim);
@@ -367,6 +430,33 @@ int vr_tree_upload(const VrTreeDesc* d, vr_tree_t* out) {
                     "tree upload failed: %s", hipGetErrorString(e));
     }
     *out = t;
+    return VR_OK;
+}
+
+int vr_tree_upload(const VrTreeDesc* d, vr_tree_t* out) { return upload_impl(d, nullptr, out); }
+
+int vr_tree_upload_quantized(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out) {
+    if (!q) return fail(VR_ERR_INVALID_ARGUMENT, "quant desc is NULL");
+    return upload_impl(d, q, out);
+}
+
+int vr_decode_quantized(const VrTreeDesc* d, const VrQuantDesc* q, uint16_t* data_out) {
+    if (!d || !q || !data_out) return fail(VR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (d->N < 2 || d->N > 16 || d->capacity <= 0 || d->data_dim < 1)
+        return fail(VR_ERR_INVALID_ARGUMENT, "bad N / capacity / data_dim");
+    if (int rc = check_quant(d, q)) return rc;
+    const size_t n_slots = (size_t)d->capacity * d->N * d->N * d->N;
+    const size_t data_sz = n_slots * (size_t)d->data_dim * sizeof(uint16_t);
+    uint16_t* d_data = data_out;
+    hipError_t e = hipSuccess;
+    if (d->memory != 1) e = hipMalloc((void**)&d_data, data_sz);
+    if (e == hipSuccess) e = decode_quant_on_device(d, q, n_slots, d_data);
+    if (e == hipSuccess && d->memory != 1)
+        e = hipMemcpy(data_out, d_data, data_sz, hipMemcpyDeviceToHost);
+    if (d->memory != 1 && d_data) (void)hipFree(d_data);
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP,
+                    "quantised decode failed: %s", hipGetErrorString(e));
     return VR_OK;
 }
 

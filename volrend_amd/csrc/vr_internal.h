@@ -109,6 +109,10 @@ int leaf_stride_halfs(int data_dim);
 hipError_t launch_relayout(const int32_t* child, const uint16_t* data, const int32_t* perm,
                            uint32_t* nodes, uint16_t* leaves, int64_t n_slots, int N3,
                            int data_dim, int stride_h, hipStream_t stream);
+// codebook decode of a quantised tree.npz into the reference's flat data layout (device)
+hipError_t launch_decode_quant(const uint16_t* colors, const uint16_t* map, const uint16_t* sigma,
+                               const uint16_t* retained, uint16_t* data, int64_t n_slots,
+                               int n_quant, int n_ret, int data_dim, hipStream_t stream);
 hipError_t launch_build_grid(const uint32_t* nodes, uint32_t* grid, int G, hipStream_t stream);
 
 }  // namespace vr

@@ -1234,6 +1234,39 @@ __global__ void relayout_leaves_kernel(const uint16_t* data, const int32_t* perm
     reinterpret_cast<uint4*>(leaves + dst * stride_h)[c] = q;
 }
 
+// Median-cut codebook decode on the device (reference host loop: src/n3tree.cpp:310-339):
+//   data[slot, j + n_ret + c*n_basis] = quant_colors[j, quant_map[j, slot], c]   j < n_quant
+//   data[slot, j + c*n_basis]         = data_retained[j, slot, c]                j < n_ret
+//   data[slot, data_dim-1]            = sigma[slot]
+// One work item per (slot, basis); the basis index is the fast one so that the three
+// 2-byte stores of neighbouring lanes land in the same lines.  `data` is zeroed first.
+__global__ void decode_quant_kernel(const uint16_t* __restrict__ colors,
+                                    const uint16_t* __restrict__ map,
+                                    const uint16_t* __restrict__ sigma,
+                                    const uint16_t* __restrict__ retained,
+                                    uint16_t* __restrict__ data, int64_t n_slots, int n_quant,
+                                    int n_ret, int data_dim) {
+    const int n_basis = n_quant + n_ret;
+    const int64_t total = n_slots * n_basis;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total;
+         w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t slot = w / n_basis;
+        const int j = (int)(w - slot * n_basis);
+        const uint16_t* c;
+        if (j < n_ret) {
+            c = retained + ((int64_t)j * n_slots + slot) * 3;
+        } else {
+            const int q = j - n_ret;
+            c = colors + ((int64_t)q * 65536 + map[(int64_t)q * n_slots + slot]) * 3;
+        }
+        uint16_t* o = data + slot * data_dim + j;
+        o[0] = c[0];
+        o[n_basis] = c[1];
+        o[2 * n_basis] = c[2];
+        if (j == 0) data[slot * data_dim + data_dim - 1] = sigma[slot];
+    }
+}
+
 // grid[cell] = deepest node at level <= G that contains the cell
 __global__ void build_grid_kernel(const uint32_t* nodes, uint32_t* grid, int G) {
     const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1375,6 +1408,20 @@ hipError_t launch_build_grid(const uint32_t* nodes, uint32_t* grid, int G, hipSt
     const uint32_t n_cells = 1u << (3 * G);
     hipLaunchKernelGGL(build_grid_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, stream, nodes,
                        grid, G);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_quant(const uint16_t* colors, const uint16_t* map, const uint16_t* sigma,
+                               const uint16_t* retained, uint16_t* data, int64_t n_slots,
+                               int n_quant, int n_ret, int data_dim, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(data, 0, (size_t)n_slots * data_dim * sizeof(uint16_t), stream);
+    if (e != hipSuccess) return e;
+    const int64_t total = n_slots * (int64_t)(n_quant + n_ret);
+    const int tpb = 256;
+    int64_t blocks = (total + tpb - 1) / tpb;
+    if (blocks > (1 << 20)) blocks = 1 << 20;  // grid-stride beyond that
+    hipLaunchKernelGGL(decode_quant_kernel, dim3((unsigned)blocks), dim3(tpb), 0, stream, colors,
+                       map, sigma, retained, data, n_slots, n_quant, n_ret, data_dim);
     return hipGetLastError();
 }
 

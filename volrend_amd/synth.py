@@ -235,7 +235,7 @@ def make_tree(depth: int, basis_dim: int = 16, fmt: str = "SH", seed: int = 0, n
 
 def make_config_tree(name: str, **overrides) -> SynthTree:
     cfg = dict(CONFIGS[name])
-    cfg.update(overrides)
+    cfg.update({k: v for k, v in overrides.items() if v is not None})
     t = make_tree(cfg["depth"], cfg["basis_dim"], cfg["fmt"], cfg["seed"], cfg["n_shapes"],
                   cfg["sigma"], shape_size=cfg.get("shape_size", (0.25, 0.6)),
                   shell_leaves=cfg.get("shell_leaves", 2.0),
