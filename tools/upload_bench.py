@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Times the step before the hot path on the GPU box: tree.npz -> device,
+through the volrend_headless CLI (C++ loader).  Three files of the C1 topology:
+  plain      stored npz (np.savez): mmap zero-copy views + vr_tree_upload
+  quantised  compress_octree.py layout (1 retained + 15 codebooks, synthetic indices),
+             device codebook decode (vr_tree_upload_quantized) vs --host_decode
+Prints one JSON object; run from the repo root:  python tools/upload_bench.py [config]"""
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from volrend_amd import synth  # noqa: E402
+
+CLI = os.path.join(ROOT, "volrend_amd", "bin", "volrend_headless")
+
+
+def run_cli(npz, pose, *flags):
+    t0 = time.perf_counter()
+    r = subprocess.run([CLI, npz, pose, "-w", "64", "-h", "64", *flags], capture_output=True,
+                       text=True, timeout=900)
+    wall = time.perf_counter() - t0
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-2000:])
+    m = re.search(r"INFO: tree ready: npz load[^0-9]* ([0-9.]+) ms, device upload[^0-9]* ([0-9.]+) ms",
+                  r.stderr)
+    return {"npz_load_ms": float(m.group(1)), "upload_ms": float(m.group(2)),
+            "process_wall_s": round(wall, 2)}
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "C1"
+    t = bench.load_or_make_tree(synth, name, 0, lambda: None)
+    work = "/dev/shm/volrend_amd_upload"
+    os.makedirs(work, exist_ok=True)
+    pose = synth.write_pose_dir(work, synth.make_poses(8)[:1], 64, 90.0)[0]
+    cap, dd = t.capacity, t.data_dim
+    nb = (dd - 1) // 3
+    n_slots = cap * 8
+    out = {"config": name, "nodes": cap, "data_bytes": int(n_slots * dd * 2)}
+
+    plain = os.path.join(work, "plain.npz")
+    synth.save_npz(t, plain)
+    out["plain_file_bytes"] = os.path.getsize(plain)
+    out["plain"] = run_cli(plain, pose)
+
+    rng = np.random.default_rng(1)
+    data = np.asarray(t.data).reshape(n_slots, dd)
+    n_ret, n_q = 1, nb - 1
+    qc = rng.standard_normal((n_q, 65536, 3)).astype(np.float16)
+    qm = rng.integers(0, 65536, (n_q, n_slots), dtype=np.uint16)
+    ret = np.ascontiguousarray(data[:, 0:3 * nb:nb])[None]  # basis 0 of R, G, B
+    quant = os.path.join(work, "quant.npz")
+    np.savez(quant, data_dim=np.int64(dd), data_format=np.array(t.data_format), child=t.child,
+             invradius3=t.invradius3, offset=t.offset, quant_colors=qc,
+             quant_map=qm.reshape(n_q, cap, 2, 2, 2), sigma=data[:, -1].reshape(cap, 2, 2, 2),
+             data_retained=ret.reshape(n_ret, cap, 2, 2, 2, 3))
+    out["quant_file_bytes"] = os.path.getsize(quant)
+    out["quant_device_decode"] = run_cli(quant, pose)
+    out["quant_host_decode"] = run_cli(quant, pose, "--host_decode")
+    for f in (plain, quant):
+        os.remove(f)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -166,6 +166,8 @@ int main(int argc, char* argv[]) {
     args.add("max_imgs", 0, false, "0", "max images to render, default no limit");
     args.add("batch", 0, false, "16", "poses per launch (1..128)");
     args.add("fp", 0, false, "strict", "floating-point model: strict | fma");
+    args.add("host_decode", 0, true, "",
+             "decode quantised trees with the host loop instead of on the device");
     try {
         internal::parse_options(args, argc, argv);
     } catch (const std::exception& e) {
@@ -212,6 +214,7 @@ int main(int argc, char* argv[]) {
     const std::string out_dir = args.str("write_images");
 
     N3Tree tree;
+    N3Tree::device_decode = !args.as_bool("host_decode");
     try {
         tree.open(args.str("file"));
     } catch (const std::exception& e) {

@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <fstream>
 #include <stdexcept>
 
@@ -85,8 +86,10 @@ void N3Tree::open(const std::string& path) {
         printf("Can't load because file does not exist: %s\n", path.c_str());
         return;
     }
+    const auto t0 = std::chrono::steady_clock::now();
     internal::NpzFile npz = internal::npz_load(path);
     load_npz(npz);
+    const auto t1 = std::chrono::steady_clock::now();
 
     use_ndc = bool(std::ifstream(poses_bounds_path_));
     if (use_ndc) {
@@ -95,7 +98,16 @@ void N3Tree::open(const std::string& path) {
         unpack_llff_poses_bounds(pb, ndc_width, ndc_height, ndc_focal, ndc_avg_up, ndc_avg_back,
                                  ndc_avg_cen);
     }
-    if (upload_on_open) load_device();
+    if (upload_on_open) {
+        const auto t2 = std::chrono::steady_clock::now();
+        load_device();
+        const auto t3 = std::chrono::steady_clock::now();
+        fprintf(stderr, "INFO: tree ready: npz load%s %.1f ms, device upload%s %.1f ms\n",
+                !quant_map_.empty() && !data_.empty() ? " + host codebook decode" : "",
+                std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                !quant_map_.empty() && data_.empty() ? " + device codebook decode" : "",
+                std::chrono::duration<double, std::milli>(t3 - t2).count());
+    }
     data_loaded_ = true;
 }
 
