@@ -20,8 +20,7 @@ for f in sorted(glob.glob(os.path.join(d, "*counter_collection.csv"))):
         for (disp, cname), v in per_dispatch.items():
             acc[meta[disp]][cname].append(v)
 for kname, counters in acc.items():
-    short = kname.split("(")[0][-60:]
-    print(f"== {short}")
+    print(f"== {kname}")
     for cname in sorted(counters):
         vals = counters[cname]
         print(f"  {cname:42s} n={len(vals):3d} mean={sum(vals)/len(vals):.6g}")
