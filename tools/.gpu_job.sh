@@ -1,8 +1,16 @@
 set -u
-export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout 600 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu3.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu3.log
-timeout 400 python bench.py > gpurun_out/bench_final3.json 2> gpurun_out/bench_final3.log; echo "bench rc=$?"; cat gpurun_out/bench_final3.json
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_final3 -o stats --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 128 --warmup 64 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_final3_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof_final3.log ); echo "prof rc=$?"
-timeout 500 python tools/upload_bench.py C1 > gpurun_out/upload_bench.json 2> gpurun_out/upload_bench.log; echo "upload rc=$?"; cat gpurun_out/upload_bench.json
-PMC_GROUPS="fetch write rdsize tcc sq1 sq2" bash tools/pmc.sh final3 > gpurun_out/pmc_final3.log 2>&1; echo "pmc rc=$?"; tail -40 gpurun_out/pmc_final3.log
+mkdir -p gpurun_out/sweep
+run() { tag=$1; shift; timeout 300 env "$@" python bench.py --no-cpu-baseline > gpurun_out/sweep/$tag.json 2> gpurun_out/sweep/$tag.log; python - <<PY
+import json
+try:
+    d=json.load(open("gpurun_out/sweep/$tag.json")); print("$tag", d["ms_per_step"], d["value"], d["roofline"]["kernel_ms_mean"])
+except Exception as e: print("$tag failed", e)
+PY
+}
+run new X=1
+run new_m2 VR_MARCH_MAX=2
+run new_m4 VR_MARCH_MAX=4
+run new_g7 VR_GRID_LEVELS=7
+timeout 300 python bench.py --batch 128 --steps 512 --warmup 128 --no-cpu-baseline 2>/dev/null | cut -c1-220
+timeout 300 python bench.py --batch 32 --no-cpu-baseline 2>/dev/null | cut -c1-220
+timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -2

@@ -30,7 +30,7 @@ int fail(int code, const char* fmt, ...) {
 // Scheduling knobs of the persistent kernel (env VR_MARCH_MAX / VR_REFILL_MIN /
 // VR_WAVES_PER_CU at first use, or vr_set_tuning).  They never change results.
 struct Tuning {
-    int march_max = 2;
+    int march_max = 3;
     int refill_min = 16;
     int waves_per_cu = 20;
     int shade_min = 48;
@@ -398,7 +398,7 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     // restart grid: N == 2 only, node ids must fit the packed entry
     t->grid_levels = 0;
     if (e == hipSuccess && d->N == 2 && max_depth <= 23 && d->capacity < (1ll << 27)) {
-        int G = 7;
+        int G = 8;
         if (const char* env = getenv("VR_GRID_LEVELS")) G = atoi(env);
         if (G > max_depth) G = max_depth;
         if (G > 8) G = 8;
