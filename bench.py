@@ -296,6 +296,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
 
+    if os.environ.get("VR_TIMELINE"):  # profiling build (-DVR_TIMELINE=1): per-phase cycle sums
+        tl = tree.sched_stats()
+        tot = max(sum(list(tl.values())[:5]), 1)
+        log("[bench] timeline (shader-clock cycles summed over waves): " + ", ".join(
+            f"{n}={v / tot:.3f}" for n, v in zip(
+                ("refill", "march", "shade_load", "shade_math", "shade_acc"), list(tl.values())[:5]))
+            + f"; wave-lifetime cycles/wave {list(tl.values())[5] / max(list(tl.values())[6], 1):.0f}"
+            + f" over {list(tl.values())[6]} waves")
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

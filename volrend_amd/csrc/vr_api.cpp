@@ -401,7 +401,7 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
         int G = 8;
         if (const char* env = getenv("VR_GRID_LEVELS")) G = atoi(env);
         if (G > max_depth) G = max_depth;
-        if (G > 8) G = 8;
+        if (G > 10) G = 10;  // 4 GB of grid at most (experiments; default 8 = 64 MB)
         if (G >= 2) {
             const size_t gsz = ((size_t)1 << (3 * G)) * sizeof(uint32_t);
             e = hipMalloc((void**)&t->grid, gsz);

@@ -22,6 +22,10 @@ constexpr int kWave = 64;
 #ifndef VR_ABLATE
 #define VR_ABLATE 0  // != 0: timing experiments that break the results (never shipped)
 #endif
+#ifndef VR_TIMELINE
+#define VR_TIMELINE 0  // 1: the FAST flavour accumulates per-phase shader-clock cycles into
+                       // sched_stats (profiling builds only; costs a few s_memtime per iteration)
+#endif
 #ifndef VR_MIN_WAVES_PER_EU
 #define VR_MIN_WAVES_PER_EU 5
 #endif
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
     __shared__ float btab[(HAS_BASIS ? NB : 1) * kWave];
     __shared__ uint32_t it_leaf[kRing];
     __shared__ float it_w[kRing];
-    __shared__ uint32_t it_own[kRing];
+    __shared__ uint8_t it_own[kRing];
     // `stage` (SH records in flight between the coalesced loads and their consumer lanes)
     // and `res` (the colour contributions) are never live at the same time: one region.
     constexpr int kStageWords = Coop<BASIS>::kEnabled ? kHalf * Coop<BASIS>::kRow / 4 : 0;
@@ -681,10 +685,21 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
     uint32_t st_march_r = 0, st_march_l = 0, st_shade_r = 0, st_shade_l = 0, st_distinct = 0,
              st_fin_r = 0, st_fin_l = 0, st_iter = 0;
 
+#if VR_TIMELINE
+    unsigned long long tl_refill = 0, tl_march = 0, tl_shade_load = 0, tl_shade_math = 0,
+                       tl_shade_acc = 0, tl_total0 = __builtin_readcyclecounter(), tl_mark = 0;
+#define TL_MARK() (tl_mark = __builtin_readcyclecounter())
+#define TL_ADD(v) do { const unsigned long long n_ = __builtin_readcyclecounter(); \
+                       (v) += n_ - tl_mark; tl_mark = n_; } while (0)
+#else
+#define TL_MARK() ((void)0)
+#define TL_ADD(v) ((void)0)
+#endif
     // Colour evaluation of up to 64 queued items, one per lane, whoever owns them;
     // afterwards every owner adds the contributions of its own items, oldest first
     // (= the reference's accumulation order, rt_core.cuh:161).
     auto shade_chunk = [&](int n) {
+        TL_ADD(tl_march);
         __syncthreads();  // item pushes are visible
         if (COUNT) {
             st_shade_r++;
@@ -704,7 +719,7 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
             using CP = Coop<BASIS>;
             const int grp = lane / CP::kLanes, vec = lane % CP::kLanes;
 #pragma unroll
-            for (int half = 0; half < kWave / kHalf; ++half) {
+            for (int half = 0; half < (kWave + kHalf - 1) / kHalf; ++half) {
                 if (half * kHalf < n) {  // wave-uniform
 #pragma unroll
                     // (one instruction may cover more records than a pass stages)
@@ -712,9 +727,18 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
                         const int r = i * CP::kPerInstr + grp;  // record within this pass
                         const int item = half * kHalf + r;
                         if (r < kHalf && item < n && vec < CP::kVec) {
+#if VR_ABLATE == 5   // timing experiment only: every record comes from a 128 KB window
+                            const uint32_t leaf =
+                                it_leaf[(ring_head + (uint32_t)item) & (kRing - 1)] & 0x3FFu;
+#else
                             const uint32_t leaf = it_leaf[(ring_head + (uint32_t)item) & (kRing - 1)];
+#endif
+#if VR_ABLATE == 4   // timing experiment only: no record load, staging kept
+                            const uint4 q = make_uint4(leaf, (uint32_t)vec, leaf, 0x3C003C00u);
+#else
                             const uint4 q = reinterpret_cast<const uint4*>(
                                 p.leaves + (uint64_t)leaf * (uint32_t)p.leaf_stride_h)[vec];
+#endif
                             *reinterpret_cast<uint4*>(
                                 reinterpret_cast<char*>(scratch) + r * CP::kRow + vec * 16) = q;
                         }
@@ -736,6 +760,7 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
                 }
             }
         }
+        TL_ADD(tl_shade_load);
         if (lane < n) {
             const uint32_t j = (ring_head + (uint32_t)lane) & (kRing - 1);
             const float weight = it_w[j];
@@ -763,6 +788,7 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
             }
         }
         __syncthreads();  // contributions are visible
+        TL_ADD(tl_shade_math);
         const uint32_t head8 = ring_head & 0xFFu;
 #pragma unroll
         for (int d = 0; d < kOwnerQ; ++d) {
@@ -783,10 +809,12 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
             }
         }
         ring_head += (uint32_t)n;
+        TL_ADD(tl_shade_acc);
     };
 
     for (;;) {
         // ---- retire finished rays and hand their lanes new ones, in batches ----
+        TL_MARK();
         const bool done = ray.active && !ray.alive && qn == 0;
         const unsigned long long m_done = __builtin_amdgcn_ballot_w64(done);
         const unsigned long long m_free = __builtin_amdgcn_ballot_w64(!ray.active);
@@ -895,6 +923,7 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
         }
 
         // ---- march: lanes with a live ray and room for another outstanding item ----
+        TL_ADD(tl_refill);
         for (int m = 0; m < p.march_max; ++m) {
             const bool go = ray.active && ray.alive && qn < kOwnerQ;
             if (!wave_any(go)) break;
@@ -968,7 +997,7 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
                     const uint32_t j = seq & (kRing - 1);
                     it_leaf[j] = leaf;
                     it_w[j] = weight;
-                    it_own[j] = (uint32_t)lane;
+                    it_own[j] = (uint8_t)lane;
                     qpos |= (seq & 0xFFu) << (8 * qn);
                     ++qn;
                 }
@@ -979,7 +1008,19 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
         // nobody can march any more (queues full / rays ended): flush what is queued
         if (ring_tail != ring_head && !wave_any(ray.active && ray.alive && qn < kOwnerQ))
             shade_chunk((int)(ring_tail - ring_head));
+        TL_ADD(tl_march);
     }
+#if VR_TIMELINE
+    if (!COUNT && p.sched_stats && lane == 0) {
+        atomicAdd(&p.sched_stats[0], tl_refill);
+        atomicAdd(&p.sched_stats[1], tl_march);
+        atomicAdd(&p.sched_stats[2], tl_shade_load);
+        atomicAdd(&p.sched_stats[3], tl_shade_math);
+        atomicAdd(&p.sched_stats[4], tl_shade_acc);
+        atomicAdd(&p.sched_stats[5], (unsigned long long)__builtin_readcyclecounter() - tl_total0);
+        atomicAdd(&p.sched_stats[6], 1ull);
+    }
+#endif
     if (COUNT && p.sched_stats && lane == 0) {
         atomicAdd(&p.sched_stats[0], (unsigned long long)st_march_r);
         atomicAdd(&p.sched_stats[1], (unsigned long long)st_march_l);
