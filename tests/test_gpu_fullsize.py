@@ -29,7 +29,7 @@ def config_tree(name):
     return bench.load_or_make_tree(synth, name, 0, lambda: None)
 
 
-@pytest.mark.parametrize("name,poses", [("C1", (0, 57, 133)), ("C2", (20,))])
+@pytest.mark.parametrize("name,poses", [("C1", (0, 57, 133)), ("C2", (20,)), ("C3", (5,))])
 def test_full_size_frames_bit_exact(torch_cuda, name, poses):
     torch = torch_cuda
     from volrend_amd import _abi, api
