@@ -148,8 +148,14 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VOLREND_BENCH_SHARE_GPU=1 (rehearsal only, never a measurement): all ranks use cuda:0 and
+    # the collectives go through gloo with host staging -- lets the N > 1 code path (shards,
+    # pipeline, assembly, self-check, rank-0 JSON) run on a one-GPU box, where RCCL refuses
+    # two ranks on one device.
+    share_gpu = os.environ.get("VOLREND_BENCH_SHARE_GPU", "0") == "1"
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # VOLREND_FORCE_GATHER=1: run the tile-shard + RCCL gather path even with one rank
     force_gather = os.environ.get("VOLREND_FORCE_GATHER", "0") == "1"
     use_dist = world > 1 or force_gather
@@ -158,10 +164,31 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         # RCCL writes its version banner to stdout; stdout carries the ONE JSON line
         os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/volrend_bench_rccl.%h.%p.log")
-        if world == 1:
+        if share_gpu:
+            dist.init_process_group("gloo")
+        elif world == 1:
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         else:
             dist.init_process_group("nccl", device_id=dev)
+
+    class _Done:
+        def wait(self):
+            return True
+
+    class HostStagedDist:
+        """gloo stand-in for the rehearsal mode: same gather() signature, host staging."""
+        @staticmethod
+        def gather(tensor, gather_list, dst=0, async_op=False):
+            torch.cuda.synchronize()
+            src = tensor.cpu()
+            outs = [torch.empty_like(src) for _ in range(world)] if rank == dst else None
+            dist.gather(src, outs, dst=dst)
+            if rank == dst:
+                for g, o in zip(gather_list, outs):
+                    g.copy_(o)
+            return _Done()
+
+    gather_dist = HostStagedDist if share_gpu else dist
 
     def barrier():
         if use_dist:
@@ -211,7 +238,7 @@ def main():
 
     # replicas: every rank is its own root and nothing is gathered
     pipe = GatherPipeline(
-        dist, rank if sharded else 0, world if sharded else 1,
+        gather_dist, rank if sharded else 0, world if sharded else 1,
         lambda: torch.zeros((B, max(nbytes, 1)), dtype=torch.uint8, device=dev),
         make_gather_list, force_collective=force_gather,
         stream_ctx=lambda j: torch.cuda.stream(streams[j % n_streams]))
@@ -305,7 +332,7 @@ def main():
             + f"; wave-lifetime cycles/wave {list(tl.values())[5] / max(list(tl.values())[6], 1):.0f}"
             + f" over {list(tl.values())[6]} waves")
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -361,7 +388,7 @@ def main():
             "scaling": "weak" if replicas else "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if share_gpu else ""),
             "config": {
                 "workload": f"{args.config}: synthetic lego-like PlenOctree, depth {cfg['depth']}, "
                             f"{cfg['fmt']}{cfg['basis_dim']}, {info['capacity']} nodes, "
