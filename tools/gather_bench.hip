@@ -35,6 +35,45 @@ __global__ __launch_bounds__(64) void gather(const uint4* __restrict__ table, ui
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// Divergent 4-byte gathers (the child-word loads of the march phase) from a table that stays
+// in the vector L1 (16 KB) or in L2 (2 MB): lane-loads per second the TA/TCP path sustains.
+template <int U>
+__global__ __launch_bounds__(64) void gather4(const uint32_t* __restrict__ table, uint32_t mask,
+                                              int iters, uint32_t* out) {
+    const uint32_t gid = blockIdx.x * 64u + threadIdx.x;
+    uint32_t acc = gid * 2654435761u;
+    for (int it = 0; it < iters; ++it) {
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = table[mix(acc + (uint32_t)u * 40503u) & mask];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u] + (uint32_t)u;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <int U>
+int run4(const uint32_t* table, uint32_t words, int waves_per_cu, int cus, uint32_t* out) {
+    const int blocks = waves_per_cu * cus;
+    const int iters = 4096 / U;
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL((gather4<U>), dim3(blocks), dim3(64), 0, 0, table, words - 1, 8, out);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    hipLaunchKernelGGL((gather4<U>), dim3(blocks), dim3(64), 0, 0, table, words - 1, iters, out);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    const double loads = (double)blocks * 64 * iters * U;
+    printf("{\"dword_gather_table_bytes\": %u, \"in_flight_per_lane\": %d, \"waves_per_cu\": %d, "
+           "\"ms\": %.3f, \"Glane_loads_per_s\": %.1f, \"wave_instr_per_us_per_cu\": %.2f}\n",
+           words * 4, U, waves_per_cu, ms, loads / ms / 1e6, loads / 64 / ms / 1e3 / cus);
+    return 0;
+}
+
 template <int U, int LANES>
 int run(const uint4* table, uint32_t n_records, int waves_per_cu, int cus, uint32_t* out) {
     const int blocks = waves_per_cu * cus;
@@ -78,6 +117,14 @@ int main() {
     for (int w : {20, 32}) {
         if (run<2, 4>(table, n_records, w, cus, out)) return 1;
         if (run<8, 4>(table, n_records, w, cus, out)) return 1;
+    }
+    // the hash makes neighbouring lanes hit unrelated words: 64 distinct lines per instruction
+    // for the 2 MB table, a 16 KB table stays in the vector L1
+    for (uint32_t words : {4096u, 524288u}) {
+        for (int w : {20, 32}) {
+            if (run4<1>((const uint32_t*)table, words, w, cus, out)) return 1;
+            if (run4<4>((const uint32_t*)table, words, w, cus, out)) return 1;
+        }
     }
     return 0;
 }

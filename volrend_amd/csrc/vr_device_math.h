@@ -55,6 +55,33 @@ static __device__ __forceinline__ float h2f(uint16_t h) {
     return (float)__builtin_bit_cast(_Float16, h);
 }
 
+// b * (float)h and fma(b, (float)h, c) with the binary16 operand taken straight from one
+// half of a packed word: v_fma_mix_f32 converts it on the fly (exact) and rounds once, so
+//   mul_half(b, w)    == b * h2f(half(w))           (the product plus -0.0 is the product),
+//   fma_half(b, w, c) == fmaf(b, h2f(half(w)), c)
+// bit for bit -- one VALU instruction instead of v_cvt_f32_f16 + v_mul_f32 / v_fma_f32.
+template <int HI>
+static __device__ __forceinline__ float mul_half(float b, uint32_t w) {
+    float d;
+    if (HI)
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]"
+            : "=v"(d) : "v"(b), "v"(w), "s"(0x80000000u));
+    else
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]"
+            : "=v"(d) : "v"(b), "v"(w), "s"(0x80000000u));
+    return d;
+}
+template <int HI>
+static __device__ __forceinline__ float fma_half(float b, uint32_t w, float c) {
+    float d;
+    if (HI)
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]"
+            : "=v"(d) : "v"(b), "v"(w), "v"(c));
+    else
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(b), "v"(w), "v"(c));
+    return d;
+}
+
 // vr_expf: the deterministic expf of DESIGN.md.  The reference calls CUDA's
 // expf (rt_core.cuh:119,160), whose bits depend on NVIDIA's ex2.approx; this is
 // a pure IEEE-op algorithm so host oracle and device agree bit for bit:

@@ -312,38 +312,47 @@ __device__ __forceinline__ void load_record(const KParams& p, uint32_t leaf, Rec
 }
 
 // SH / SG colour of channel c: rt_core.cuh:125-165.  Group order 25 -> 16 -> 9
-// -> 4, each group summed left to right, then added to tmp.
-template <int FMA, int BASIS>
-__device__ __forceinline__ float channel_dot(const float* basis_fn, const Record<BASIS>& r,
-                                             int c) {
-    using P = Policy<FMA>;
-    if (BASIS == BASIS_1) return basis_fn[0] * r.at(c);
-    const int o = c * BASIS;
-    float tmp = basis_fn[0] * r.at(o);
-    if (BASIS == 25) {
-        float g = P::madd(basis_fn[16], r.at(o + 16), basis_fn[17] * r.at(o + 17));
-#pragma unroll
-        for (int i = 18; i <= 24; ++i) g = P::madd(basis_fn[i], r.at(o + i), g);
-        tmp += g;
+// -> 4, each group summed left to right, then added to tmp.  Coefficient e of the record is
+// half (e & 1) of word e >> 1; products read it in place (mul_half / fma_half).
+template <int BASIS, int E>
+__device__ __forceinline__ float coef_mul(float b, const Record<BASIS>& r) {
+    return mul_half<E & 1>(b, r.w[E >> 1]);
+}
+template <int FMA, int BASIS, int E>  // Policy<FMA>::madd(b, coefficient E, c)
+__device__ __forceinline__ float coef_madd(float b, const Record<BASIS>& r, float c) {
+    if (FMA) return fma_half<E & 1>(b, r.w[E >> 1], c);
+    return mul_half<E & 1>(b, r.w[E >> 1]) + c;
+}
+// g = b[LO]*v[LO] (+) b[LO+1]*v[LO+1] (+) ... (+) b[HI]*v[HI], coefficients at offset O
+template <int FMA, int BASIS, int O, int LO, int HI>
+struct DotGroup {
+    template <int I>
+    static __device__ __forceinline__ float step(const float* b, const Record<BASIS>& r, float g) {
+        if constexpr (I > HI) {
+            return g;
+        } else {
+            return step<I + 1>(b, r, coef_madd<FMA, BASIS, O + I>(b[I], r, g));
+        }
     }
-    if (BASIS >= 16) {
-        float g = P::madd(basis_fn[9], r.at(o + 9), basis_fn[10] * r.at(o + 10));
-#pragma unroll
-        for (int i = 11; i <= 15; ++i) g = P::madd(basis_fn[i], r.at(o + i), g);
-        tmp += g;
+    static __device__ __forceinline__ float run(const float* b, const Record<BASIS>& r) {
+        const float first = coef_madd<FMA, BASIS, O + LO>(b[LO], r, coef_mul<BASIS, O + LO + 1>(b[LO + 1], r));
+        return step<LO + 2>(b, r, first);
     }
-    if (BASIS >= 9) {
-        float g = P::madd(basis_fn[4], r.at(o + 4), basis_fn[5] * r.at(o + 5));
-#pragma unroll
-        for (int i = 6; i <= 8; ++i) g = P::madd(basis_fn[i], r.at(o + i), g);
-        tmp += g;
+};
+
+template <int FMA, int BASIS, int C>
+__device__ __forceinline__ float channel_dot(const float* basis_fn, const Record<BASIS>& r) {
+    if constexpr (BASIS == BASIS_1 || BASIS == BASIS_RGBA) {
+        return basis_fn[0] * r.at(C);
+    } else {
+        constexpr int O = C * BASIS;
+        float tmp = coef_mul<BASIS, O>(basis_fn[0], r);
+        if constexpr (BASIS == 25) tmp += DotGroup<FMA, BASIS, O, 16, 24>::run(basis_fn, r);
+        if constexpr (BASIS >= 16) tmp += DotGroup<FMA, BASIS, O, 9, 15>::run(basis_fn, r);
+        if constexpr (BASIS >= 9) tmp += DotGroup<FMA, BASIS, O, 4, 8>::run(basis_fn, r);
+        if constexpr (BASIS >= 4) tmp += DotGroup<FMA, BASIS, O, 1, 3>::run(basis_fn, r);
+        return tmp;
     }
-    if (BASIS >= 4) {
-        float g = P::madd(basis_fn[1], r.at(o + 1), basis_fn[2] * r.at(o + 2));
-        g = P::madd(basis_fn[3], r.at(o + 3), g);
-        tmp += g;
-    }
-    return tmp;
 }
 
 __device__ __forceinline__ uint32_t quant8(float v) {
@@ -770,17 +779,21 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
                 float b[NB];
 #pragma unroll
                 for (int i = 0; i < NB; ++i) b[i] = btab[i * kWave + own];
+#if VR_ABLATE == 3   // timing experiment only: loads kept, SH / sigmoid arithmetic removed
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-#if VR_ABLATE == 3   // timing experiment only: loads kept, SH / sigmoid arithmetic removed
                     uint32_t x = 0;
                     for (int i = 0; i < RecTraits<BASIS>::kDwords; ++i) x ^= rec.w[i];
                     res[c * kRing + j] = weight * u2f((x & 0x007FFFFFu) | 0x3F000000u) * b[c];
-#else
-                    const float tmp = channel_dot<FMA, BASIS>(b, rec, c);
-                    res[c * kRing + j] = weight / (1.f + vr_expf(-tmp));
-#endif
                 }
+#else
+                const float tmp0 = channel_dot<FMA, BASIS, 0>(b, rec);
+                const float tmp1 = channel_dot<FMA, BASIS, 1>(b, rec);
+                const float tmp2 = channel_dot<FMA, BASIS, 2>(b, rec);
+                res[0 * kRing + j] = weight / (1.f + vr_expf(-tmp0));
+                res[1 * kRing + j] = weight / (1.f + vr_expf(-tmp1));
+                res[2 * kRing + j] = weight / (1.f + vr_expf(-tmp2));
+#endif
             } else {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) res[c * kRing + j] = rec.at(c);
