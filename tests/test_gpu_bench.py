@@ -1,0 +1,61 @@
+"""-m gpu: the driver contract of bench.py (one JSON line on stdout with the agreed keys) and a
+rehearsal of its N > 1 path with two ranks sharing the one GPU (gloo, host-staged gather)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C0", "--steps",
+                        "16", "--warmup", "8", "--batch", "8"], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+              "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+              "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 16 and d["warmup"] == 8
+    assert d["unit"] == "Mrays/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and "workload" in d["config"]
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+
+
+@pytest.mark.parametrize("mode", ["tile", "replicas"])
+def test_bench_multirank_rehearsal(gpu, mode):
+    env = dict(os.environ, VOLREND_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                        "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C0",
+                        "--steps", "16", "--warmup", "8", "--batch", "4", "--no-cpu-baseline",
+                        "--mode", mode], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "REHEARSAL" in d["data"]
+    if mode == "tile":
+        assert d["scaling"] == "strong"
+        assert d["config"]["sharded_frame_matches_single_gpu"] is True
+    else:
+        assert d["scaling"] == "weak" and "replicas" in d["config"]["parallelism"]

@@ -2,7 +2,7 @@
 // Same command line, pose / intrinsics file formats, PNG naming and the two result lines
 // ("%.10f ms per frame", "%.10f fps") as the reference's main_headless.cpp; the device
 // work goes through the C ABI (include/volrend_hip.h).  Poses are known up front, so they
-// are rendered in batches of --batch frames per launch (default 16).
+// are rendered in batches of --batch frames per launch (default 32).
 #include <hip/hip_runtime.h>
 
 #include <condition_variable>
@@ -164,7 +164,7 @@ int main(int argc, char* argv[]) {
     args.add("reverse_yz", 'r', true, "", "use OpenCV camera space convention instead of NeRF");
     args.add("scale", 0, false, "1.0", "scaling to apply to image");
     args.add("max_imgs", 0, false, "0", "max images to render, default no limit");
-    args.add("batch", 0, false, "16", "poses per launch (1..128)");
+    args.add("batch", 0, false, "32", "poses per launch (1..128)");
     args.add("fp", 0, false, "strict", "floating-point model: strict | fma");
     args.add("host_decode", 0, true, "",
              "decode quantised trees with the host loop instead of on the device");
