@@ -272,6 +272,10 @@ struct RecTraits {
 template <int BASIS>
 struct Record {
     uint32_t w[RecTraits<BASIS>::kDwords];
+    template <int E>  // the packed word that holds coefficient E
+    __device__ __forceinline__ uint32_t word() const {
+        return w[E >> 1];
+    }
     // coefficient i (compile-time) as fp32
     __device__ __forceinline__ float at(int i) const {
         const uint32_t d = w[i >> 1];
@@ -314,45 +318,67 @@ __device__ __forceinline__ void load_record(const KParams& p, uint32_t leaf, Rec
 // SH / SG colour of channel c: rt_core.cuh:125-165.  Group order 25 -> 16 -> 9
 // -> 4, each group summed left to right, then added to tmp.  Coefficient e of the record is
 // half (e & 1) of word e >> 1; products read it in place (mul_half / fma_half).
-template <int BASIS, int E>
-__device__ __forceinline__ float coef_mul(float b, const Record<BASIS>& r) {
-    return mul_half<E & 1>(b, r.w[E >> 1]);
+// The 16-byte chunks of a staged record (LDS row) that hold channel C's coefficients.
+template <int BASIS, int C>
+struct ChanWin {
+    static constexpr int kFirst = (C * BASIS) / 8;
+    static constexpr int kLast = (C * BASIS + BASIS - 1) / 8;
+    static constexpr int kChunks = kLast - kFirst + 1;
+    uint32_t w[kChunks * 4];
+    __device__ __forceinline__ void load(const char* row) {
+#pragma unroll
+        for (int q = 0; q < kChunks; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4*>(row + (kFirst + q) * 16);
+            w[4 * q + 0] = v.x;
+            w[4 * q + 1] = v.y;
+            w[4 * q + 2] = v.z;
+            w[4 * q + 3] = v.w;
+        }
+    }
+    template <int E>
+    __device__ __forceinline__ uint32_t word() const {
+        return w[(E >> 1) - kFirst * 4];
+    }
+};
+
+template <int E, typename SRC>
+__device__ __forceinline__ float coef_mul(float b, const SRC& r) {
+    return mul_half<E & 1>(b, r.template word<E>());
 }
-template <int FMA, int BASIS, int E>  // Policy<FMA>::madd(b, coefficient E, c)
-__device__ __forceinline__ float coef_madd(float b, const Record<BASIS>& r, float c) {
-    if (FMA) return fma_half<E & 1>(b, r.w[E >> 1], c);
-    return mul_half<E & 1>(b, r.w[E >> 1]) + c;
+template <int FMA, int E, typename SRC>  // Policy<FMA>::madd(b, coefficient E, c)
+__device__ __forceinline__ float coef_madd(float b, const SRC& r, float c) {
+    if (FMA) return fma_half<E & 1>(b, r.template word<E>(), c);
+    return mul_half<E & 1>(b, r.template word<E>()) + c;
 }
 // g = b[LO]*v[LO] (+) b[LO+1]*v[LO+1] (+) ... (+) b[HI]*v[HI], coefficients at offset O
-template <int FMA, int BASIS, int O, int LO, int HI>
+template <int FMA, int O, int LO, int HI>
 struct DotGroup {
-    template <int I>
-    static __device__ __forceinline__ float step(const float* b, const Record<BASIS>& r, float g) {
+    template <int I, typename SRC>
+    static __device__ __forceinline__ float step(const float* b, const SRC& r, float g) {
         if constexpr (I > HI) {
             return g;
         } else {
-            return step<I + 1>(b, r, coef_madd<FMA, BASIS, O + I>(b[I], r, g));
+            return step<I + 1>(b, r, coef_madd<FMA, O + I>(b[I], r, g));
         }
     }
-    static __device__ __forceinline__ float run(const float* b, const Record<BASIS>& r) {
-        const float first = coef_madd<FMA, BASIS, O + LO>(b[LO], r, coef_mul<BASIS, O + LO + 1>(b[LO + 1], r));
+    template <typename SRC>
+    static __device__ __forceinline__ float run(const float* b, const SRC& r) {
+        const float first = coef_madd<FMA, O + LO>(b[LO], r, coef_mul<O + LO + 1>(b[LO + 1], r));
         return step<LO + 2>(b, r, first);
     }
 };
 
-template <int FMA, int BASIS, int C>
-__device__ __forceinline__ float channel_dot(const float* basis_fn, const Record<BASIS>& r) {
-    if constexpr (BASIS == BASIS_1 || BASIS == BASIS_RGBA) {
-        return basis_fn[0] * r.at(C);
-    } else {
-        constexpr int O = C * BASIS;
-        float tmp = coef_mul<BASIS, O>(basis_fn[0], r);
-        if constexpr (BASIS == 25) tmp += DotGroup<FMA, BASIS, O, 16, 24>::run(basis_fn, r);
-        if constexpr (BASIS >= 16) tmp += DotGroup<FMA, BASIS, O, 9, 15>::run(basis_fn, r);
-        if constexpr (BASIS >= 9) tmp += DotGroup<FMA, BASIS, O, 4, 8>::run(basis_fn, r);
-        if constexpr (BASIS >= 4) tmp += DotGroup<FMA, BASIS, O, 1, 3>::run(basis_fn, r);
-        return tmp;
-    }
+// SRC = Record<BASIS> (whole record in registers) or ChanWin<BASIS, C> (channel window)
+template <int FMA, int BASIS, int C, typename SRC>
+__device__ __forceinline__ float channel_dot(const float* basis_fn, const SRC& r) {
+    static_assert(BASIS > 1, "SH / SG / ASG sizes only");
+    constexpr int O = C * BASIS;
+    float tmp = coef_mul<O>(basis_fn[0], r);
+    if constexpr (BASIS == 25) tmp += DotGroup<FMA, O, 16, 24>::run(basis_fn, r);
+    if constexpr (BASIS >= 16) tmp += DotGroup<FMA, O, 9, 15>::run(basis_fn, r);
+    if constexpr (BASIS >= 9) tmp += DotGroup<FMA, O, 4, 8>::run(basis_fn, r);
+    if constexpr (BASIS >= 4) tmp += DotGroup<FMA, O, 1, 3>::run(basis_fn, r);
+    return tmp;
 }
 
 __device__ __forceinline__ uint32_t quant8(float v) {
@@ -616,50 +642,61 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
 //   0-2 cen, 3-5 dir, 6-8 invdir, 9 t, 10 tmax, 11 delta_scale, 12 xy,
 //   13 pix_off, 14 frame, 15.. basis_fn[0..nb)
 // Wave-private LDS of the march kernel (one wave per workgroup):
-//   btab : basis_fn[i] of the ray currently held by lane l at word i*64 + l
-//   ring : colour work items (leaf, weight, owner lane) in sample order, and the
-//          three colour contributions computed for each of them
+//   ring  : colour work items (leaf, weight, owner lane) in sample order
+//   stage : the SH records of one shade round, DMA'd straight from HBM (global_load_lds)
+//   res   : the three colour contributions of each item of the round
+// The basis of a lane's ray lives in that lane's registers; the lane that shades one of its
+// items reads it through the LDS crossbar (ds_bpermute).
 // ---------------------------------------------------------------------------
 constexpr int kRayWords = 15;
 constexpr int kRing = 128;   // capacity; at most 127 items are ever outstanding
-#ifndef VR_STAGE_RECORDS
-#define VR_STAGE_RECORDS 16
-#endif
 constexpr int kQueueStride = 16;  // words between queue heads (one 64-byte line each)
-constexpr int kHalf = VR_STAGE_RECORDS;  // records staged per pass of the cooperative loader
 
-// Cooperative, line-coalesced record loads: a record of V 16-byte vectors is fetched by a
-// group of L = pow2(V) adjacent lanes (one cache line per group instead of one line per
-// lane and vector), parked in LDS with an odd row pitch (bank-conflict-free 128-bit
-// reads) and picked up whole by the lane that shades it.
+// Record fetch of a shade round: a record of V 16-byte chunks is fetched by V adjacent lanes
+// (one or two cache lines per group instead of one line per lane and chunk) with LDS-DMA loads:
+// lane l of an instruction lands at base + 16*l, i.e. records sit in dense rows of V*16 bytes
+// and nothing passes through registers.  All records of a round (SH25: of half a round) are in
+// flight at once; one wait, then every lane reads the row of the item it shades.
 template <int BASIS>
-struct Coop {
+struct Stage {
     static constexpr bool kEnabled = BASIS > 1;
-    static constexpr int kVec = RecTraits<BASIS>::kDwords / 4;                  // V
-    static constexpr int kLanes = kVec <= 2 ? 2 : kVec <= 4 ? 4 : kVec <= 8 ? 8 : 16;  // L
-    static constexpr int kPerInstr = kWave / kLanes;                            // records per load
-    static constexpr int kRow = (kVec | 1) * 16;                                // bytes, odd * 16
+    static constexpr int kVec = kEnabled ? RecTraits<BASIS>::kDwords / 4 : 1;  // V: 2, 4, 6, 10
+    static constexpr int kRow = kVec * 16;                            // bytes
+    static constexpr int kPerInstr = kWave / kVec;                    // records per DMA instruction
+    static constexpr int kPass = kRow * kWave <= 6144 ? kWave : kWave / 2;  // records per pass
+    static constexpr int kInstr = (kPass + kPerInstr - 1) / kPerInstr;
+    static constexpr int kBytes = kEnabled ? kPass * kRow : 16;
 };
+typedef __attribute__((address_space(1))) const void* vr_gptr_t;
+typedef __attribute__((address_space(3))) void* vr_lptr_t;
 constexpr int kOwnerQ = 4;   // outstanding items per ray (8-bit ring positions in one VGPR)
 
+// Register budget: 5 waves/SIMD (<= 96 VGPRs) for the production flavours; the SH25 and the
+// instrumented / generic flavours keep their wider state in registers at 4 waves/SIMD.
+template <int BASIS, int MODE>
+constexpr int min_waves_per_eu() {
+    return (BASIS == BASIS_25 || MODE != MODE_FAST) && VR_MIN_WAVES_PER_EU > 4 ? 4
+                                                                                : VR_MIN_WAVES_PER_EU;
+}
+
 template <int FMA, int BASIS, int MODE>
-__global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(const KParams p) {
+__global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void render_kernel(
+    const KParams p) {
     using P = Policy<FMA>;
     constexpr bool N2 = MODE != MODE_GENERIC;
     constexpr bool LOBES = MODE != MODE_FAST;
     constexpr bool COUNT = MODE != MODE_FAST;
     constexpr int NB = BASIS > 1 ? BASIS : 1;
     constexpr bool HAS_BASIS = BASIS != BASIS_RGBA;
-    __shared__ float btab[(HAS_BASIS ? NB : 1) * kWave];
+    using ST = Stage<BASIS>;
     __shared__ uint32_t it_leaf[kRing];
     __shared__ float it_w[kRing];
     __shared__ uint8_t it_own[kRing];
-    // `stage` (SH records in flight between the coalesced loads and their consumer lanes)
-    // and `res` (the colour contributions) are never live at the same time: one region.
-    constexpr int kStageWords = Coop<BASIS>::kEnabled ? kHalf * Coop<BASIS>::kRow / 4 : 0;
-    constexpr int kScratchWords = kStageWords > 3 * kRing ? kStageWords : 3 * kRing;
-    __shared__ __attribute__((aligned(16))) uint32_t scratch[kScratchWords];
-    float* const res = reinterpret_cast<float*>(scratch);
+    __shared__ __attribute__((aligned(16))) char stage[ST::kBytes];
+    __shared__ float res[3 * kWave];
+    float mybasis[NB];  // basis_fn of this lane's ray (rt_core.cuh:96-103), read by shader lanes
+#pragma unroll
+    for (int i = 0; i < NB; ++i) mybasis[i] = 0.f;
 
     const int lane = threadIdx.x & (kWave - 1);
     Ray ray;
@@ -723,99 +760,108 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
             }
             st_distinct += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(first));
         }
-        Record<BASIS> rec;
-        if (Coop<BASIS>::kEnabled) {
-            using CP = Coop<BASIS>;
-            const int grp = lane / CP::kLanes, vec = lane % CP::kLanes;
+        const bool have = lane < n;
+        const uint32_t jmine = (ring_head + (uint32_t)lane) & (kRing - 1);
+        const float weight = have ? it_w[jmine] : 0.f;
+        // the basis of the ray that owns my item, out of its lane's registers (every lane
+        // executes the permutes: a bpermute only reads active lanes)
+        float b[NB];
+        if (HAS_BASIS) {
+            const int own4 = have ? (int)it_own[jmine] << 2 : lane << 2;
 #pragma unroll
-            for (int half = 0; half < (kWave + kHalf - 1) / kHalf; ++half) {
-                if (half * kHalf < n) {  // wave-uniform
+            for (int i = 0; i < NB; ++i)
+                b[i] = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(own4, (int)f2u(mybasis[i])));
+        }
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        if constexpr (ST::kEnabled) {
 #pragma unroll
-                    // (one instruction may cover more records than a pass stages)
-                    for (int i = 0; i < (kHalf + CP::kPerInstr - 1) / CP::kPerInstr; ++i) {
-                        const int r = i * CP::kPerInstr + grp;  // record within this pass
-                        const int item = half * kHalf + r;
-                        if (r < kHalf && item < n && vec < CP::kVec) {
+            for (int pass = 0; pass < kWave / ST::kPass; ++pass) {
+                if (pass * ST::kPass < n) {  // wave-uniform
+#pragma unroll
+                    for (int k = 0; k < ST::kInstr; ++k) {
+                        const int rin = k * ST::kPerInstr + lane / ST::kVec;  // record within the pass
+                        const int item = pass * ST::kPass + rin;
+                        if (lane < ST::kPerInstr * ST::kVec && rin < ST::kPass && item < n) {
 #if VR_ABLATE == 5   // timing experiment only: every record comes from a 128 KB window
                             const uint32_t leaf =
                                 it_leaf[(ring_head + (uint32_t)item) & (kRing - 1)] & 0x3FFu;
 #else
                             const uint32_t leaf = it_leaf[(ring_head + (uint32_t)item) & (kRing - 1)];
 #endif
-#if VR_ABLATE == 4   // timing experiment only: no record load, staging kept
-                            const uint4 q = make_uint4(leaf, (uint32_t)vec, leaf, 0x3C003C00u);
-#else
-                            const uint4 q = reinterpret_cast<const uint4*>(
-                                p.leaves + (uint64_t)leaf * (uint32_t)p.leaf_stride_h)[vec];
+                            const char* src = reinterpret_cast<const char*>(p.leaves) +
+                                              (uint64_t)leaf * (uint32_t)(p.leaf_stride_h * 2) +
+                                              (lane % ST::kVec) * 16;
+#if VR_ABLATE != 4   // 4 = timing experiment only: no record fetch at all
+                            __builtin_amdgcn_global_load_lds(
+                                (vr_gptr_t)src, (vr_lptr_t)(stage + k * ST::kPerInstr * ST::kRow), 16, 0, 0);
 #endif
-                            *reinterpret_cast<uint4*>(
-                                reinterpret_cast<char*>(scratch) + r * CP::kRow + vec * 16) = q;
                         }
                     }
-                    __syncthreads();  // the half is staged
-                    if ((lane / kHalf) == half && lane < n) {
-                        const char* row =
-                            reinterpret_cast<const char*>(scratch) + (lane % kHalf) * CP::kRow;
-#pragma unroll
-                        for (int v = 0; v < CP::kVec; ++v) {
-                            const uint4 q = *reinterpret_cast<const uint4*>(row + v * 16);
-                            rec.w[4 * v + 0] = q.x;
-                            rec.w[4 * v + 1] = q.y;
-                            rec.w[4 * v + 2] = q.z;
-                            rec.w[4 * v + 3] = q.w;
+                    __syncthreads();  // the DMAs have landed (vmcnt(0)) and are visible
+                    TL_ADD(tl_shade_load);
+                    if (have && lane / ST::kPass == pass) {
+                        const char* row = stage + (lane % ST::kPass) * ST::kRow;
+#if VR_ABLATE == 3   // timing experiment only: loads kept, SH / sigmoid arithmetic removed
+                        const uint4 v = *reinterpret_cast<const uint4*>(row);
+                        r0 = weight * u2f((v.x & 0x007FFFFFu) | 0x3F000000u) * b[0];
+                        r1 = weight * u2f((v.y & 0x007FFFFFu) | 0x3F000000u) * b[1];
+                        r2 = weight * u2f((v.z & 0x007FFFFFu) | 0x3F000000u) * b[2];
+#else
+                        {
+                            ChanWin<BASIS, 0> cw;
+                            cw.load(row);
+                            r0 = weight / (1.f + vr_expf(-channel_dot<FMA, BASIS, 0>(b, cw)));
                         }
+                        {
+                            ChanWin<BASIS, 1> cw;
+                            cw.load(row);
+                            r1 = weight / (1.f + vr_expf(-channel_dot<FMA, BASIS, 1>(b, cw)));
+                        }
+                        {
+                            ChanWin<BASIS, 2> cw;
+                            cw.load(row);
+                            r2 = weight / (1.f + vr_expf(-channel_dot<FMA, BASIS, 2>(b, cw)));
+                        }
+#endif
                     }
-                    __syncthreads();  // the staging area may be overwritten
+                    if (ST::kPass < kWave) __syncthreads();  // rows are free for the next pass
+                    TL_ADD(tl_shade_math);
                 }
+            }
+        } else if (have) {
+            Record<BASIS> rec;
+            load_record<BASIS>(p, it_leaf[jmine], rec);
+            if (HAS_BASIS) {  // runtime basis size: first coefficient of each channel only
+                r0 = weight / (1.f + vr_expf(-(b[0] * rec.at(0))));
+                r1 = weight / (1.f + vr_expf(-(b[0] * rec.at(1))));
+                r2 = weight / (1.f + vr_expf(-(b[0] * rec.at(2))));
+            } else {  // RGBA: out[c] = madd(colour, weight, out[c]) is formed by the owner
+                r0 = rec.at(0);
+                r1 = rec.at(1);
+                r2 = rec.at(2);
             }
         }
-        TL_ADD(tl_shade_load);
-        if (lane < n) {
-            const uint32_t j = (ring_head + (uint32_t)lane) & (kRing - 1);
-            const float weight = it_w[j];
-            const uint32_t own = it_own[j];
-            if (!Coop<BASIS>::kEnabled) load_record<BASIS>(p, it_leaf[j], rec);
-            if (HAS_BASIS) {
-                float b[NB];
-#pragma unroll
-                for (int i = 0; i < NB; ++i) b[i] = btab[i * kWave + own];
-#if VR_ABLATE == 3   // timing experiment only: loads kept, SH / sigmoid arithmetic removed
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    uint32_t x = 0;
-                    for (int i = 0; i < RecTraits<BASIS>::kDwords; ++i) x ^= rec.w[i];
-                    res[c * kRing + j] = weight * u2f((x & 0x007FFFFFu) | 0x3F000000u) * b[c];
-                }
-#else
-                const float tmp0 = channel_dot<FMA, BASIS, 0>(b, rec);
-                const float tmp1 = channel_dot<FMA, BASIS, 1>(b, rec);
-                const float tmp2 = channel_dot<FMA, BASIS, 2>(b, rec);
-                res[0 * kRing + j] = weight / (1.f + vr_expf(-tmp0));
-                res[1 * kRing + j] = weight / (1.f + vr_expf(-tmp1));
-                res[2 * kRing + j] = weight / (1.f + vr_expf(-tmp2));
-#endif
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) res[c * kRing + j] = rec.at(c);
-                // RGBA: out[c] = madd(colour, weight, out[c]) is formed by the owner
-            }
+        if (have) {
+            res[0 * kWave + lane] = r0;
+            res[1 * kWave + lane] = r1;
+            res[2 * kWave + lane] = r2;
         }
         __syncthreads();  // contributions are visible
         TL_ADD(tl_shade_math);
         const uint32_t head8 = ring_head & 0xFFu;
 #pragma unroll
         for (int d = 0; d < kOwnerQ; ++d) {
-            if (qn > 0 && (((qpos & 0xFFu) - head8) & 0xFFu) < (uint32_t)n) {
-                const uint32_t j = qpos & (kRing - 1);
+            const uint32_t idx = ((qpos & 0xFFu) - head8) & 0xFFu;  // item index within the round
+            if (qn > 0 && idx < (uint32_t)n) {
                 if (HAS_BASIS) {
-                    ray.out[0] += res[0 * kRing + j];
-                    ray.out[1] += res[1 * kRing + j];
-                    ray.out[2] += res[2 * kRing + j];
+                    ray.out[0] += res[0 * kWave + idx];
+                    ray.out[1] += res[1 * kWave + idx];
+                    ray.out[2] += res[2 * kWave + idx];
                 } else {
-                    const float weight = it_w[j];
-                    ray.out[0] = P::madd(res[0 * kRing + j], weight, ray.out[0]);
-                    ray.out[1] = P::madd(res[1 * kRing + j], weight, ray.out[1]);
-                    ray.out[2] = P::madd(res[2 * kRing + j], weight, ray.out[2]);
+                    const float w = it_w[qpos & (kRing - 1)];
+                    ray.out[0] = P::madd(res[0 * kWave + idx], w, ray.out[0]);
+                    ray.out[1] = P::madd(res[1 * kWave + idx], w, ray.out[1]);
+                    ray.out[2] = P::madd(res[2 * kWave + idx], w, ray.out[2]);
                 }
                 qpos >>= 8;
                 --qn;
@@ -915,7 +961,7 @@ __global__ __launch_bounds__(kWave, VR_MIN_WAVES_PER_EU) void render_kernel(cons
                         if (HAS_BASIS) {
 #pragma unroll
                             for (int i = 0; i < NB; ++i)
-                                btab[i * kWave + lane] = u2f(rb[(size_t)(kRayWords + i) * cap]);
+                                mybasis[i] = u2f(rb[(size_t)(kRayWords + i) * cap]);
                         }
                         ray.out[0] = ray.out[1] = ray.out[2] = ray.out[3] = 0.f;
                         ray.light = 1.f;
