@@ -30,8 +30,8 @@ int fail(int code, const char* fmt, ...) {
 // Scheduling knobs of the persistent kernel (env VR_MARCH_MAX / VR_REFILL_MIN /
 // VR_WAVES_PER_CU at first use, or vr_set_tuning).  They never change results.
 struct Tuning {
-    int march_max = 3;
-    int refill_min = 16;
+    int march_max = 16;
+    int refill_min = 24;
     int waves_per_cu = 20;
     int shade_min = 48;
     int frame_minor = 1;

@@ -669,7 +669,11 @@ struct Stage {
 };
 typedef __attribute__((address_space(1))) const void* vr_gptr_t;
 typedef __attribute__((address_space(3))) void* vr_lptr_t;
-constexpr int kOwnerQ = 4;   // outstanding items per ray (8-bit ring positions in one VGPR)
+#ifndef VR_OWNER_Q
+#define VR_OWNER_Q 4
+#endif
+constexpr int kOwnerQ = VR_OWNER_Q;  // outstanding items per ray (8-bit ring positions, packed)
+typedef std::conditional<(VR_OWNER_Q > 4), uint64_t, uint32_t>::type qpos_t;
 
 // Register budget: 5 waves/SIMD (<= 96 VGPRs) for the production flavours; the SH25 and the
 // instrumented / generic flavours keep their wider state in registers at 4 waves/SIMD.
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     ray.out[0] = ray.out[1] = ray.out[2] = ray.out[3] = 0.f;
     RayCounters rc;
     Cursor cur;
-    uint32_t qpos = 0;  // up to kOwnerQ ring positions (8 bits each), oldest in the low byte
+    qpos_t qpos = 0;  // up to kOwnerQ ring positions (8 bits each), oldest in the low byte
     int qn = 0;
     // wave-uniform scheduler state
     bool exhausted = false;  // the ray buffer has been handed out completely
@@ -851,14 +855,14 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         const uint32_t head8 = ring_head & 0xFFu;
 #pragma unroll
         for (int d = 0; d < kOwnerQ; ++d) {
-            const uint32_t idx = ((qpos & 0xFFu) - head8) & 0xFFu;  // item index within the round
+            const uint32_t idx = ((uint32_t)(qpos & 0xFFu) - head8) & 0xFFu;  // item index within the round
             if (qn > 0 && idx < (uint32_t)n) {
                 if (HAS_BASIS) {
                     ray.out[0] += res[0 * kWave + idx];
                     ray.out[1] += res[1 * kWave + idx];
                     ray.out[2] += res[2 * kWave + idx];
                 } else {
-                    const float w = it_w[qpos & (kRing - 1)];
+                    const float w = it_w[(uint32_t)qpos & (kRing - 1)];
                     ray.out[0] = P::madd(res[0 * kWave + idx], w, ray.out[0]);
                     ray.out[1] = P::madd(res[1 * kWave + idx], w, ray.out[1]);
                     ray.out[2] = P::madd(res[2 * kWave + idx], w, ray.out[2]);
@@ -1057,7 +1061,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     it_leaf[j] = leaf;
                     it_w[j] = weight;
                     it_own[j] = (uint8_t)lane;
-                    qpos |= (seq & 0xFFu) << (8 * qn);
+                    qpos |= (qpos_t)(seq & 0xFFu) << (8 * qn);
                     ++qn;
                 }
                 ring_tail += (uint32_t)__builtin_popcountll(m_push);
