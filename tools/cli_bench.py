@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""volrend_headless end to end on the C1 workload (200 poses, 800x800): the reference's own timing
+lines with and without PNG output.  Run on the GPU box from the repo root; prints one JSON object."""
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from volrend_amd import synth  # noqa: E402
+
+CLI = os.path.join(ROOT, "volrend_amd", "bin", "volrend_headless")
+
+
+def run(args):
+    t0 = time.perf_counter()
+    r = subprocess.run([CLI, *args], capture_output=True, text=True, timeout=900)
+    wall = time.perf_counter() - t0
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-2000:])
+    ms = float(re.search(r"([0-9.]+) ms per frame", r.stdout).group(1))
+    fps = float(re.search(r"([0-9.]+) fps", r.stdout).group(1))
+    return {"ms_per_frame": round(ms, 4), "fps": round(fps, 1), "process_wall_s": round(wall, 2)}
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "C1"
+    cfg = synth.CONFIGS[name]
+    t = bench.load_or_make_tree(synth, name, 0, lambda: None)
+    work = "/dev/shm/volrend_amd_cli"
+    shutil.rmtree(work, ignore_errors=True)
+    os.makedirs(work)
+    npz = os.path.join(work, "tree.npz")
+    synth.save_npz(t, npz)
+    poses = synth.write_pose_dir(work, synth.make_poses(200), cfg["width"], cfg["focal"])
+    common = [npz, *poses, "-i", os.path.join(work, "intrinsics.txt"), "-w", str(cfg["width"]),
+              "-h", str(cfg["height"])]
+    out = {"config": name, "poses": len(poses)}
+    out["timing_only"] = run(common)
+    out["timing_only_batch64"] = run(common + ["--batch", "64"])
+    out["write_png"] = run(common + ["-o", os.path.join(work, "out")])
+    out["png_files"] = len(os.listdir(os.path.join(work, "out")))
+    shutil.rmtree(work, ignore_errors=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
