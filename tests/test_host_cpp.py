@@ -146,3 +146,47 @@ def test_large_stored_members_are_viewed_zero_copy(exe, tmp_path):
     assert parse_kv(out[0])["capacity"] == str(t.capacity)
     kv = parse_kv(out[3])
     assert int(kv["child_fnv"]) == fnv_np(t.child) and int(kv["data_fnv"]) == fnv_np(t.data)
+
+
+def test_cli_pose_and_intrinsics_parsing(tmp_path):
+    """Pose / intrinsics text formats of the reference CLI (main_headless.cpp:40-75): 4x4 and 3x4
+    matrices, stacked 4x4, a file that ends inside a matrix, trailing junk, -r column flips."""
+    cli = os.path.join(ROOT, "volrend_amd", "bin", "volrend_headless")
+    if not os.path.exists(cli):
+        subprocess.check_call(["make", "-C", ROOT, "cli"], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(3)
+    a, b = rng.normal(size=(4, 4)), rng.normal(size=(4, 4))
+    f44, f34, fst, fcut, fjunk = (str(tmp_path / n) for n in
+                                  ("a44.txt", "a34.txt", "stack.txt", "cut.txt", "junk.txt"))
+    np.savetxt(f44, a)
+    np.savetxt(f34, a[:3])
+    np.savetxt(fst, np.concatenate([a, b]))
+    open(fcut, "w").write(" ".join(f"{x:.9g}" for x in a.reshape(-1)[:7]))       # ends in row 2
+    open(fjunk, "w").write(" ".join(f"{x:.9g}" for x in a.reshape(-1)[:12]) + " # comment 1 2 3")
+    K = np.diag([555.5, 444.25, 1.0, 1.0])
+    fk = str(tmp_path / "intrinsics.txt")
+    np.savetxt(fk, K)
+
+    def dump(*args):
+        r = subprocess.run([cli, "tree.npz", *args, "--dump_poses"], capture_output=True, text=True,
+                           timeout=60)
+        assert r.returncode == 0, r.stderr
+        poses = [l.split() for l in r.stdout.splitlines() if l.startswith("pose ")]
+        intr = [l.split() for l in r.stdout.splitlines() if l.startswith("intrin ")]
+        return ({p[1]: np.array(p[2:], dtype=np.float64).reshape(4, 3).T for p in poses}, intr)
+
+    poses, intr = dump(f44, f34, fst, fcut, fjunk, "-i", fk)
+    want = np.float32(a[:3])
+    assert np.allclose(poses["a44"], want, rtol=1e-6) and np.allclose(poses["a34"], want, rtol=1e-6)
+    assert np.allclose(poses["stack_000000"], want, rtol=1e-6)
+    assert np.allclose(poses["stack_000001"], np.float32(b[:3]), rtol=1e-6)
+    cut = np.zeros(12)
+    cut[:7] = a.reshape(-1)[:7]
+    assert np.allclose(poses["cut"], np.float32(cut.reshape(3, 4)), rtol=1e-6)
+    assert np.allclose(poses["junk"], want, rtol=1e-6)
+    assert len(poses) == 6
+    assert float(intr[0][1]) == pytest.approx(555.5) and float(intr[0][2]) == pytest.approx(444.25)
+    flipped, _ = dump(f44, "-r")
+    assert np.allclose(flipped["a44"][:, 1], -want[:, 1], rtol=1e-6)
+    assert np.allclose(flipped["a44"][:, 2], -want[:, 2], rtol=1e-6)
+    assert np.allclose(flipped["a44"][:, [0, 3]], want[:, [0, 3]], rtol=1e-6)

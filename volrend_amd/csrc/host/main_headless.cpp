@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <condition_variable>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
@@ -47,38 +48,45 @@ std::string remove_ext(const std::string& str) {
     return p == std::string::npos ? str : str.substr(0, p);
 }
 
-// A pose file holds one or more row-major 3x4 / 4x4 matrices (main_headless.cpp:40-63);
-// each becomes a column-major 4x3 (right, up, back, centre).
-int read_transform_matrices(const std::string& path, std::vector<glm::mat4x3>& out) {
+// Every leading float of a text file (parsing stops at the first token that is not a number,
+// which is where formatted stream extraction would stop, too).
+std::vector<float> leading_floats(const std::string& path, const char* what) {
     std::ifstream ifs(path);
     if (!ifs) {
-        fprintf(stderr, "ERROR: '%s' does not exist\n", path.c_str());
+        fprintf(stderr, "ERROR: %s'%s' does not exist\n", what, path.c_str());
         std::exit(1);
     }
+    std::vector<float> v;
+    for (float x; ifs >> x;) v.push_back(x);
+    return v;
+}
+
+// A pose file holds one or more row-major matrices (reference main_headless.cpp:40-63): twelve
+// numbers are the three rows of a camera-to-world matrix; when more numbers follow, the next four
+// are taken to be its 4th row and skipped (so stacked matrices must be 4x4).  A matrix whose
+// first row is complete counts even if the file ends inside it (missing entries = 0).  Each
+// becomes a column-major 4x3: right, up, back, centre.
+int read_transform_matrices(const std::string& path, std::vector<glm::mat4x3>& out) {
+    const std::vector<float> v = leading_floats(path, "");
     int cnt = 0;
-    while (ifs) {
-        glm::mat4x3 m;
-        float garb;
-        ifs >> m[0][0] >> m[1][0] >> m[2][0] >> m[3][0];
-        if (!ifs) break;
-        ifs >> m[0][1] >> m[1][1] >> m[2][1] >> m[3][1];
-        ifs >> m[0][2] >> m[1][2] >> m[2][2] >> m[3][2];
-        if (ifs) ifs >> garb >> garb >> garb >> garb;  // optional 4th row
-        ++cnt;
+    for (size_t at = 0; v.size() - at >= 4;) {
+        const size_t have = std::min<size_t>(12, v.size() - at);
+        glm::mat4x3 m{};
+        for (size_t k = 0; k < have; ++k) m[(int)(k % 4)][(int)(k / 4)] = v[at + k];
         out.push_back(m);
+        ++cnt;
+        if (have < 12) break;
+        at += 12 + std::min<size_t>(4, v.size() - at - 12);
     }
     return cnt;
 }
 
+// intrinsics.txt is a 4x4 K matrix; only K[0][0] and K[1][1] are used (main_headless.cpp:65-75).
 void read_intrins(const std::string& path, float& fx, float& fy) {
-    std::ifstream ifs(path);
-    if (!ifs) {
-        fprintf(stderr, "ERROR: intrin '%s' does not exist\n", path.c_str());
-        std::exit(1);
-    }
-    float g;
-    ifs >> fx >> g >> g >> g;
-    ifs >> g >> fy;
+    const std::vector<float> v = leading_floats(path, "intrin ");
+    fx = v.empty() ? 0.f : v[0];
+    if (v.size() >= 6) fy = v[5];
+    else if (v.size() == 5) fy = 0.f;  // the extraction that runs into the end of file zeroes its target
 }
 
 // Frame egress (reference main_headless.cpp:216-222 writes each PNG inline and calls it
@@ -166,6 +174,7 @@ int main(int argc, char* argv[]) {
     args.add("max_imgs", 0, false, "0", "max images to render, default no limit");
     args.add("batch", 0, false, "32", "poses per launch (1..128)");
     args.add("fp", 0, false, "strict", "floating-point model: strict | fma");
+    args.add("dump_poses", 0, true, "", "print the parsed poses / intrinsics and exit (no GPU needed)");
     args.add("host_decode", 0, true, "",
              "decode quantised trees with the host loop instead of on the device");
     try {
@@ -206,6 +215,20 @@ int main(int argc, char* argv[]) {
         }
     } else {
         puts("INFO: Use NeRF camera convention\n");
+    }
+    if (args.as_bool("dump_poses")) {
+        for (size_t i = 0; i < trans.size(); ++i) {
+            printf("pose %s", basenames[i].c_str());
+            for (int c = 0; c < 4; ++c)
+                printf(" %.9g %.9g %.9g", trans[i][c].x, trans[i][c].y, trans[i][c].z);
+            printf("\n");
+        }
+        if (!args.str("intrin").empty()) {
+            float fx = -1.f, fy = -1.f;
+            read_intrins(args.str("intrin"), fx, fy);
+            printf("intrin %.9g %.9g\n", fx, fy);
+        }
+        return 0;
     }
     if (trans.empty()) {
         fputs("WARNING: No camera poses specified, quitting\n", stderr);

@@ -158,6 +158,9 @@ void N3Tree::load_npz(internal::NpzFile& npz) {
     child_ = std::move(need("child"));
     if (child_.kind != 'i' || child_.word_size != 4 || child_.shape.size() != 4)
         throw std::runtime_error("child must be int32 [capacity, N, N, N]");
+    if (child_.shape[1] < 2 || child_.shape[1] > 16 || child_.shape[2] != child_.shape[1] ||
+        child_.shape[3] != child_.shape[1] || child_.shape[0] == 0 || child_.shape[0] > 0x7FFFFFFFu)
+        throw std::runtime_error("child must be int32 [capacity, N, N, N] with 2 <= N <= 16");
     N = (int)child_.shape[1];
     if (N != 2) fprintf(stderr, "WARNING: N != 2 is rendered by the generic (slower) kernel.\n");
     N2_ = N * N;
@@ -186,6 +189,16 @@ void N3Tree::load_npz(internal::NpzFile& npz) {
             (!data_retained_.empty() && data_retained_.word_size != 2))
             throw std::runtime_error("quantised arrays must be 16-bit");
         data_ = internal::NpyArray();
+        {  // every codebook array is indexed per slot: check before anything reads them
+            const size_t n_slots = (size_t)capacity * N3_;
+            const size_t n_ret = data_retained_.empty() ? 0 : data_retained_.shape[0];
+            if ((size_t)capacity != child_.shape[0] || data_dim < 1 || data_dim > 4096 ||
+                quant_map_.num_vals != n_q * n_slots || sigma_.num_vals != n_slots ||
+                quant_colors_.num_vals != n_q * 65536 * 3 ||
+                (n_ret && data_retained_.num_vals != n_ret * n_slots * 3) ||
+                3 * (n_q + n_ret) + 1 > (size_t)data_dim)
+                throw std::runtime_error("quantised arrays do not match capacity / data_dim");
+        }
         if (!(device_decode && upload_on_open)) decode_quantized_host();
     } else {
         internal::NpyArray& d = need("data");
@@ -195,6 +208,10 @@ void N3Tree::load_npz(internal::NpzFile& npz) {
     }
     if ((size_t)capacity != child_.shape[0])
         throw std::runtime_error("child and data disagree on the capacity");
+    if (data_dim < 1 || data_dim > 4096) throw std::runtime_error("data_dim out of range");
+    const size_t n_slots = (size_t)capacity * N3_;
+    if (!data_.empty() && data_.num_vals != n_slots * (size_t)data_dim)
+        throw std::runtime_error("data does not have capacity * N^3 * data_dim values");
     if (npz.count("extra_data"))
         extra_ = std::move(npz["extra_data"]);
     else

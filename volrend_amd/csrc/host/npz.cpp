@@ -9,6 +9,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <future>
@@ -44,6 +45,8 @@ void parse_header(const std::string& h, NpyArray& a) {
         if (d.size() < 3) fail("unsupported dtype " + d);
         if (d[0] == '>') fail("big-endian arrays are not supported");
         a.kind = d[1];
+        if (d.find_first_not_of("0123456789", 2) != std::string::npos) fail("unsupported dtype " + d);
+        if (d.size() > 8) fail("unsupported dtype " + d);
         const size_t n = (size_t)std::stoul(d.substr(2));
         a.word_size = a.kind == 'U' ? n * 4 : n;  // numpy stores UCS4
     }
@@ -64,12 +67,17 @@ void parse_header(const std::string& h, NpyArray& a) {
             size_t j = i;
             while (j < r && h[j] >= '0' && h[j] <= '9') ++j;
             if (j == i) fail("malformed shape");
+            if (j - i > 18) fail("malformed shape");
             a.shape.push_back((size_t)std::stoull(h.substr(i, j - i)));
             i = j;
         }
     }
+    if (a.word_size == 0 || a.word_size > 1024 || a.shape.size() > 16) fail("unsupported array header");
     a.num_vals = 1;
-    for (size_t s : a.shape) a.num_vals *= s;
+    for (size_t s : a.shape) {
+        if (s != 0 && a.num_vals > (SIZE_MAX / a.word_size) / s) fail("array size overflows");
+        a.num_vals *= s;
+    }
 }
 
 // Parses the npy preamble; returns the offset of the raw data.
@@ -106,6 +114,11 @@ struct Member {
     uint64_t csize, usize, local_off;
 };
 
+// [off, off + len) lies inside the archive (no wrap-around for hostile 64-bit fields)
+inline bool inside(uint64_t off, uint64_t len, size_t size) {
+    return off <= size && len <= size - off;
+}
+
 std::vector<Member> central_directory(const uint8_t* b, size_t size) {
     if (size < 22) fail("file too small for a zip archive");
     // end of central directory record: scan backwards for its signature
@@ -122,31 +135,39 @@ std::vector<Member> central_directory(const uint8_t* b, size_t size) {
     uint64_t cd_off = rd32(b + eocd + 16);
     if (eocd >= 20 && rd32(b + eocd - 20) == 0x07064b50u) {  // ZIP64 locator
         const uint64_t z64 = rd64(b + eocd - 20 + 8);
-        if (z64 + 56 > size || rd32(b + z64) != 0x06064b50u) fail("bad zip64 record");
+        if (!inside(z64, 56, size) || rd32(b + z64) != 0x06064b50u) fail("bad zip64 record");
         n_entries = rd64(b + z64 + 32);
         cd_off = rd64(b + z64 + 48);
     }
     std::vector<Member> out;
     uint64_t p = cd_off;
     for (uint64_t e = 0; e < n_entries; ++e) {
-        if (p + 46 > size || rd32(b + p) != 0x02014b50u) fail("bad central directory entry");
+        if (!inside(p, 46, size) || rd32(b + p) != 0x02014b50u) fail("bad central directory entry");
         Member m;
         m.method = rd16(b + p + 10);
         m.csize = rd32(b + p + 20);
         m.usize = rd32(b + p + 24);
         const uint16_t fn = rd16(b + p + 28), ex = rd16(b + p + 30), cm = rd16(b + p + 32);
         m.local_off = rd32(b + p + 42);
+        if (!inside(p + 46, (uint64_t)fn + ex + cm, size)) fail("central directory entry is truncated");
         m.name.assign(reinterpret_cast<const char*>(b + p + 46), fn);
         // ZIP64 extended information: only the saturated fields are present, in order
         uint64_t q = p + 46 + fn;
         const uint64_t qend = q + ex;
         while (q + 4 <= qend) {
             const uint16_t id = rd16(b + q), len = rd16(b + q + 2);
+            if (q + 4 + len > qend) fail("bad extra field in the central directory");
             if (id == 0x0001) {
                 uint64_t r = q + 4;
-                if (m.usize == 0xFFFFFFFFu) { m.usize = rd64(b + r); r += 8; }
-                if (m.csize == 0xFFFFFFFFu) { m.csize = rd64(b + r); r += 8; }
-                if (m.local_off == 0xFFFFFFFFu) { m.local_off = rd64(b + r); r += 8; }
+                const uint64_t rend = q + 4 + len;
+                auto take = [&](uint64_t& field) {
+                    if (r + 8 > rend) fail("zip64 extra field is too short");
+                    field = rd64(b + r);
+                    r += 8;
+                };
+                if (m.usize == 0xFFFFFFFFu) take(m.usize);
+                if (m.csize == 0xFFFFFFFFu) take(m.csize);
+                if (m.local_off == 0xFFFFFFFFu) take(m.local_off);
             }
             q += 4 + len;
         }
@@ -158,11 +179,11 @@ std::vector<Member> central_directory(const uint8_t* b, size_t size) {
 
 NpyArray load_member(const uint8_t* b, size_t size, const Member& m,
                      const std::shared_ptr<void>& mapping) {
-    if (m.local_off + 30 > size || rd32(b + m.local_off) != 0x04034b50u)
+    if (!inside(m.local_off, 30, size) || rd32(b + m.local_off) != 0x04034b50u)
         fail("bad local header for " + m.name);
     const uint16_t fn = rd16(b + m.local_off + 26), ex = rd16(b + m.local_off + 28);
     const uint64_t data_off = m.local_off + 30 + fn + ex;
-    if (data_off + m.csize > size) fail("member " + m.name + " exceeds the archive");
+    if (!inside(data_off, m.csize, size)) fail("member " + m.name + " exceeds the archive");
     NpyArray a;
     if (m.method == 0) {  // stored
         const size_t pre = parse_npy_preamble(b + data_off, (size_t)m.csize, a);
@@ -176,6 +197,8 @@ NpyArray load_member(const uint8_t* b, size_t size, const Member& m,
             a.data_holder.assign(b + data_off + pre, b + data_off + pre + want);
         }
     } else if (m.method == 8) {  // deflate: inflate the whole member, then strip the preamble
+        // deflate cannot expand by more than ~1032:1; a larger claim is a corrupt header
+        if (m.usize / 1040 > m.csize + 64) fail("member " + m.name + " claims an impossible size");
         std::vector<uint8_t> raw((size_t)m.usize);
         z_stream zs;
         std::memset(&zs, 0, sizeof(zs));
