@@ -1,5 +1,5 @@
-// volrend::DataFormat -- same type and semantics as the reference's
-// include/volrend/data_format.hpp:8-25 (parse: src/n3tree.cpp:55-78).
+// volrend::DataFormat: what a leaf record holds (reference include/volrend/data_format.hpp:8-25;
+// the "SH16" / "SG25" / "RGBA" strings of tree.npz are parsed as src/n3tree.cpp:55-78 does).
 #pragma once
 #include <string>
 
@@ -8,21 +8,11 @@
 namespace volrend {
 
 struct DataFormat {
-    enum {
-        RGBA,  // Simply stores rgba
-        SH,
-        SG,
-        ASG,
-        _COUNT,
-    } format = RGBA;
+    enum Kind { RGBA, SH, SG, ASG, _COUNT };  // RGBA: colour stored directly; the others: a basis
+    Kind format = RGBA;
+    int basis_dim = -1;  // basis functions per colour channel (-1 for RGBA)
 
-    // SH/SG/ASG dimension per channel
-    int basis_dim = -1;
-
-    // Parse a string like 'SH16', 'SG25'
-    void parse(const std::string& str);
-
-    // Convert to string
+    void parse(const std::string& str);  // "SH16" -> {SH, 16}; anything unknown -> RGBA
     std::string to_string() const;
 };
 

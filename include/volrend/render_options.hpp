@@ -1,35 +1,32 @@
-// volrend::RenderOptions -- field for field the reference's
-// include/volrend/render_options.hpp:11-53 (render_depth is always present: the device
-// backend always exists here).
+// volrend::RenderOptions: the per-frame knobs of the ray march.  Names, types and defaults are
+// those of the reference (include/volrend/render_options.hpp:11-53) so that callers compile
+// unchanged; VrRenderOptions (volrend_hip.h) is the C-ABI image of this struct.  `render_depth`
+// exists unconditionally: the device backend is always present here.
 #pragma once
 #include "volrend/common.hpp"
 
-// Max global basis
-#define VOLREND_GLOBAL_BASIS_MAX 25
+#define VOLREND_GLOBAL_BASIS_MAX 25  // most basis functions per channel (SH degree 4)
 
 namespace volrend {
 
 struct RenderOptions {
-    // * BASIC RENDERING
-    float step_size = 1e-4f;      // epsilon added to steps to avoid re-hitting the current box
-    float sigma_thresh = 1e-2f;   // sigma below this counts as 0
-    float stop_thresh = 1e-2f;    // stop marching when the remaining light is below this
+    // -- marching (rt_core.cuh:108-188)
+    float step_size = 1e-4f, sigma_thresh = 1e-2f, stop_thresh = 1e-2f;
+    //    step_size: added to every leaf-exit distance; sigma_thresh: densities up to this are
+    //    skipped; stop_thresh: a ray ends once its remaining light falls below this
     float background_brightness = 1.f;
 
-    // * VISUALIZATION
-    // [minx, miny, minz, maxx, maxy, maxz] relative to the tree bounding box [0, 1]
-    float render_bbox[6] = {0.f, 0.f, 0.f, 1.f, 1.f, 1.f};
-    // Range of basis functions to use (no effect for RGBA)
-    int basis_minmax[2] = {0, VOLREND_GLOBAL_BASIS_MAX - 1};
-    // Rotation applied to viewdirs for all rays
-    float rot_dirs[3] = {0.f, 0.f, 0.f};
+    // -- what is shown
+    float render_bbox[6] = {0.f, 0.f, 0.f, 1.f, 1.f, 1.f};    // min xyz, max xyz in tree space [0, 1]
+    int basis_minmax[2] = {0, VOLREND_GLOBAL_BASIS_MAX - 1};  // basis functions outside are zeroed
+    float rot_dirs[3] = {0.f, 0.f, 0.f};                      // axis-angle turn of every view direction
+    bool render_depth = false;                                // grey depth image instead of colour
 
-    // * ADVANCED VISUALIZATION
+    // -- carried for source compatibility: the device kernel ignores them, as upstream's does
     bool show_grid = false;
     int grid_max_depth = 4;
-    bool render_depth = false;
 
-    // * Probe for inspecting lumispheres
+    // -- lumisphere probe (volrend.cu:100-134, 175-191)
     bool enable_probe = false;
     float probe[3] = {0.f, 0.f, 1.f};
     int probe_disp_size = 100;
