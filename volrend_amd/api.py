@@ -155,6 +155,8 @@ class N3Tree:
 
     def _set_arrays(self, child, data, offset, invradius3, data_format, extra, data_dim=None):
         child = np.ascontiguousarray(child, dtype=np.int32)
+        if child.ndim != 4 or not (child.shape[1] == child.shape[2] == child.shape[3]):
+            raise RuntimeError("child must be int32 [capacity, N, N, N]")
         self.N = int(child.shape[1])
         self.capacity = int(child.shape[0])
         self.child_ = child.reshape(self.capacity, self.N, self.N, self.N)
@@ -168,6 +170,8 @@ class N3Tree:
                 raise RuntimeError("data must be stored in half precision")  # n3tree.cpp:344-346
             self.data_ = np.ascontiguousarray(data)
             self.data_dim = int(self.data_.shape[-1])
+            if self.data_.size != self.capacity * self.N ** 3 * self.data_dim:
+                raise RuntimeError("data does not have capacity * N^3 * data_dim values")
         self.data_format = parse_data_format(data_format)
         self.scale = np.asarray(invradius3, dtype=np.float32).reshape(3).copy()
         self.offset = np.asarray(offset, dtype=np.float32).reshape(3).copy()
@@ -333,6 +337,8 @@ def _quant_arrays(z, child) -> dict:
     if qc.shape[0] != n_q:
         raise RuntimeError("codebook and map basis numbers does not match")
     cap, N = qm.shape[1], child.shape[1]
+    if cap != child.shape[0] or qc.shape[1:] != (65536, 3):
+        raise RuntimeError("quantised arrays do not match the tree")
     n_slots = cap * N * N * N
     retained = z["data_retained"] if "data_retained" in z.files else None
     return dict(
