@@ -70,39 +70,58 @@ def load_or_make_tree(synth, name: str, local_rank: int, barrier, seed=None):
                            dict(config=name))
 
 
-def cpu_baseline(tree, transforms, width, height, focal, budget_s=12.0):
-    """Oracle (strict mode) on all host cores over a bounded sample of the same workload:
-    whole frames of the pose orbit, one after the other, until ~budget_s of wall time is
-    spent (at least one frame; a 64-row centre band first if a frame would not fit)."""
+def _time_cpu(render, label, kind, cores, transforms, width, height, focal, budget_s):
+    """Bounded sample of the bench workload on the host: whole frames of the pose orbit, one after
+    the other, until ~budget_s of wall time is spent (at least one frame; only a 64-row centre
+    band of pose 0 if a whole frame would not fit the budget)."""
+    y0 = max(0, (height // 2 - 32) // 8 * 8)
+    rows = min(64, height - y0)
+    t0 = time.perf_counter()
+    render(transforms[0], (0, y0, width, rows))
+    t_band = time.perf_counter() - t0
+    if t_band * height / rows > 2.5 * budget_s:  # slow host: the band is the sample
+        return {"value": round(width * rows / t_band / 1e6, 4), "unit": "Mrays/s", "cores": cores,
+                "kind": kind,
+                "sample": f"{rows}-row centre band of pose 0 ({width * rows} rays), "
+                          f"{t_band:.1f}s, {label}, {cores} threads"}
+    rays, t_total, n = 0, 0.0, 0
+    while t_total < budget_s and n < len(transforms):
+        t0 = time.perf_counter()
+        render(transforms[n], None)
+        t_total += time.perf_counter() - t0
+        rays += width * height
+        n += 1
+    return {"value": round(rays / t_total / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": kind,
+            "sample": f"{n} full {width}x{height} frames (poses 0..{n - 1}, {rays} rays), "
+                      f"{t_total:.1f}s, {label}, {cores} threads"}
+
+
+def cpu_baseline(tree, transforms, width, height, focal, budget_s=8.0):
+    """The same frames on the host cores.  kind "reference": the reference's own render_kernel
+    (src/cuda/volrend.cu + rt_core.cuh compiled for the host, oracle/_ref -- present when
+    build() ran where the reference is mounted); kind "port": the oracle's C restatement, always
+    timed and reported next to it."""
     from oracle import binding as ob
     th = ob.TreeHandle(tree)
     opt = ob.default_options()
     cores = os.cpu_count() or 1
-    cam = ob.make_camera(transforms[0], width, height, focal)
-    y0 = max(0, (height // 2 - 32) // 8 * 8)
-    rows = min(64, height - y0)
-    t0 = time.perf_counter()
-    ob.render(th, cam, opt, ob.FP_STRICT, region=(0, y0, width, rows), want_accum=False,
-              nthreads=cores)
-    t_band = time.perf_counter() - t0
-    est_frame = t_band * height / rows
-    if est_frame > 2.5 * budget_s:  # slow host: the band is the sample
-        mrays = width * rows / t_band / 1e6
-        return {"value": round(mrays, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                "sample": f"{rows}-row centre band of pose 0 ({width * rows} rays), "
-                          f"{t_band:.1f}s, oracle strict mode, {cores} threads"}
-    rays, t_total, n = 0, 0.0, 0
-    while t_total < budget_s and n < len(transforms):
-        cam = ob.make_camera(transforms[n], width, height, focal)
-        t0 = time.perf_counter()
-        ob.render(th, cam, opt, ob.FP_STRICT, want_accum=False, nthreads=cores)
-        t_total += time.perf_counter() - t0
-        rays += width * height
-        n += 1
-    mrays = rays / t_total / 1e6
-    return {"value": round(mrays, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{n} full {width}x{height} frames (poses 0..{n - 1}, {rays} rays), "
-                      f"{t_total:.1f}s, oracle strict mode, {cores} threads"}
+
+    def port(tr, region):
+        ob.render(th, ob.make_camera(tr, width, height, focal), opt, ob.FP_STRICT, region=region,
+                  want_accum=False, nthreads=cores)
+
+    out = _time_cpu(port, "oracle strict mode", "port", cores, transforms, width, height, focal,
+                    budget_s)
+    if ob.ref_lib(False) is not None:
+        def ref(tr, region):
+            ob.ref_render(th, ob.make_camera(tr, width, height, focal), opt, region=region,
+                          nthreads=cores)
+
+        r = _time_cpu(ref, "reference render_kernel compiled for the host (g++ -O2)", "reference",
+                      cores, transforms, width, height, focal, budget_s)
+        r["port"] = {"value": out["value"], "sample": out["sample"]}
+        out = r
+    return out
 
 
 def main():

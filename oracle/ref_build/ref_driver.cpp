@@ -120,14 +120,19 @@ int ref_render(const RefTree* td, const RefCamera* cd, const RefOptions* od, int
     VrShimSurface img{rgba, (size_t)cd->width * 4, cd->width * 4, cd->height};
     VrShimSurface dep{reinterpret_cast<uint8_t*>(depth), (size_t)cd->width * 4, cd->width * 4,
                       cd->height};
-    std::atomic<int> next{0};
+    // work items = spans of 64 pixels of the rectangle (rows differ a lot in cost: a row per
+    // item leaves most of a many-core host idle at the end of the frame)
+    const long long n_px = (long long)w * h;
+    std::atomic<long long> next{0};
     auto work = [&]() {
         blockDim.x = 1;
         threadIdx.x = 0;
         for (;;) {
-            const int row = next.fetch_add(1);
-            if (row >= h) break;
-            for (int x = x0; x < x0 + w; ++x) {
+            const long long first = next.fetch_add(64);
+            if (first >= n_px) break;
+            const long long last = first + 64 < n_px ? first + 64 : n_px;
+            for (long long i = first; i < last; ++i) {
+                const int row = (int)(i / w), x = x0 + (int)(i % w);
                 blockIdx.x = (unsigned)((y0 + row) * cd->width + x);
                 device::render_kernel(&img, depth ? &dep : nullptr, internal::CameraSpec(cam),
                                       internal::TreeSpec(tree), opt,
