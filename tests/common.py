@@ -111,3 +111,32 @@ def write_quantised_npz(tree, path, n_retain=1, compressed=True):
         ret = np.stack([coeff[:, :, j] for j in range(n_retain)])  # [n_ret, slot, 3]
         arrays["data_retained"] = ret.reshape(n_retain, cap, N, N, N, 3)
     (np.savez_compressed if compressed else np.savez)(path, **arrays)
+
+
+def random_configuration(seed):
+    """Seeded random (tree, transform, w, h, focal, ndc, option kwargs): formats, basis sizes,
+    odd image sizes, cameras inside the volume, degenerate thresholds, bbox / basis range /
+    view rotation / depth mode, NDC."""
+    import numpy as np
+    rng = np.random.default_rng(9000 + seed)
+    fmt, bd = [("SH", 1), ("SH", 4), ("SH", 9), ("SH", 16), ("SH", 25), ("RGBA", 0), ("SG", 4),
+               ("SG", 16), ("ASG", 9), ("SG", 7)][int(rng.integers(10))]
+    tree = small_scene(depth=int(rng.integers(3, 7)), basis_dim=bd, fmt=fmt,
+                       seed=int(rng.integers(1 << 30)))
+    w, h = int(rng.integers(9, 70)), int(rng.integers(9, 70))
+    tr = np.array(camera_for(pose_idx=int(rng.integers(8)), size=64)[0], dtype=np.float32)
+    tr[9:12] *= np.float32(rng.choice([1.0, 0.6, 0.25, 0.05]))  # move towards / into the volume
+    focal = float(rng.uniform(0.4, 2.5) * w)
+    lo = rng.uniform(0.0, 0.4, 3)
+    hi = rng.uniform(0.6, 1.0, 3)
+    bmin = int(rng.integers(0, 3))
+    kw = dict(step_size=float(10 ** rng.uniform(-5, -2)),
+              sigma_thresh=float(rng.choice([0.0, 1e-2, 0.5, 20.0])),
+              stop_thresh=float(rng.choice([0.0, 1e-3, 1e-2, 0.3])),
+              background_brightness=float(rng.choice([0.0, 0.5, 1.0])),
+              render_bbox=tuple(lo) + tuple(hi) if rng.random() < 0.5 else (0, 0, 0, 1, 1, 1),
+              basis_minmax=(bmin, int(rng.integers(bmin, 25))) if rng.random() < 0.4 else (0, 24),
+              rot_dirs=tuple(rng.normal(size=3) * 0.7) if rng.random() < 0.3 else (0, 0, 0),
+              render_depth=int(rng.random() < 0.2))
+    ndc = (float(w), float(h), float(focal)) if rng.random() < 0.25 else None
+    return tree, tr, w, h, focal, ndc, kw, (fmt, bd)

@@ -288,3 +288,17 @@ def test_quantised_upload_rejects_bad_descriptors(torch_cuda):
     q.sigma = sig.ctypes.data
     assert L.vr_tree_upload_quantized(C.byref(d), C.byref(q), C.byref(h)) == 0
     L.vr_tree_free(h)
+
+
+@pytest.mark.parametrize("fp_mode", [0, 1])
+def test_random_configurations_bit_exact(torch_cuda, fp_mode):
+    """The seeded sweep of tests/test_oracle_vs_ref.py (random format / basis size / tree /
+    camera / options / NDC, odd image sizes, cameras inside the volume) on the GPU."""
+    for seed in range(24):
+        tree, tr, w, h, focal, ndc, kw, what = common.random_configuration(seed)
+        rgba_o, acc_o, _ = common.oracle_frame(tree, tr, w, h, focal, fp_mode, ndc=ndc, **kw)
+        rgba_g, acc_g = gpu_frame(torch_cuda, tree, tr, w, h, focal, fp_mode, ndc=ndc, **kw)
+        try:
+            assert_parity(rgba_g, acc_g, rgba_o, acc_o)
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed} {what} {kw}: {e}") from None

@@ -154,3 +154,15 @@ def test_general_branching_factor_bit_exact(N, depth, fmt, basis_dim):
     assert np.array_equal(rgba_o, rgba_r)
     assert np.array_equal(acc_o.view(np.uint32), ob.ref_trace(th, cam, opt).view(np.uint32))
     assert (rgba_o[..., :3] != 255).any()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations_bit_exact(seed):
+    """Seeded sweep of the pin: random format / basis size / tree / camera / options (including
+    odd image sizes, cameras inside the volume, degenerate thresholds and NDC) -- RGBA8 and fp32
+    accumulators of the oracle equal the reference host build's bit for bit."""
+    tree, tr, w, h, focal, ndc, kw, (fmt, bd) = common.random_configuration(seed)
+    rgba_o, acc_o, rgba_r, (th, cam, opt) = both(tree, tr, w, h, focal, ndc=ndc, **kw)
+    assert np.array_equal(rgba_o, rgba_r), (fmt, bd, kw)
+    acc_r = ob.ref_trace(th, cam, opt)
+    assert np.array_equal(acc_o.view(np.uint32), acc_r.view(np.uint32)), (fmt, bd, kw)
