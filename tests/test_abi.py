@@ -133,3 +133,23 @@ def test_bad_trees_are_rejected_on_the_host(lib_path):
     dag[0, 1] = 1  # two slots share one child
     rc, msg = try_upload(dag)
     assert rc == 4
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under volrend_amd/ or include/ may import, link
+    or even name it, and the library must not fall back to a CPU path (it raises instead)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = []
+    for top in ("volrend_amd", "include"):
+        for d, _, files in os.walk(os.path.join(root, top)):
+            for f in files:
+                if not f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                    continue
+                text = open(os.path.join(d, f), errors="ignore").read()
+                if re.search(r"\bimport\s+oracle\b|\bfrom\s+oracle\b|oracle/|vr_oracle|libvr_oracle", text):
+                    offenders.append(os.path.join(d, f))
+    assert not offenders, offenders
+    makefile = open(os.path.join(root, "Makefile")).read()
+    lib_rules = makefile.split("oracle:")[0]  # everything before the oracle target
+    assert "vr_oracle" not in lib_rules
