@@ -74,3 +74,54 @@ def test_loader_survives_corrupted_archives(asan_exe, tmp_path):
             assert r.returncode >= 0, f"loader died with signal {-r.returncode}"
             assert "AddressSanitizer" not in err and "runtime error" not in err, err[-1500:]
     assert n_cases > 300 and n_rejected > 50
+
+
+def test_loader_rejects_wrong_rank_arrays(asan_exe, tmp_path):
+    """Well-formed archives whose arrays have the wrong RANK (a byte-flip fuzzer never makes
+    these): 1-D quant_map, 0-d data / quant_colors / data_retained, short offset / invradius3.
+    Every one must be refused with an error -- no out-of-bounds shape read, no null deref."""
+    import numpy as np
+    tree = synth.make_tree(depth=3, basis_dim=4, seed=6)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    plain = str(tmp_path / "plain.npz")
+    synth.save_npz(tree, plain, compressed=False)
+    quant = str(tmp_path / "quant.npz")
+    common.write_quantised_npz(tree, quant, n_retain=1, compressed=False)
+
+    def variant(src, name, **replace):
+        z = dict(np.load(src))
+        for k, v in replace.items():
+            if v is None:
+                z.pop(k, None)
+            else:
+                z[k] = v
+        p = str(tmp_path / name)
+        np.savez(p, **z)
+        return p
+
+    zq = np.load(quant)
+    cases = [
+        variant(plain, "data_0d.npz", data=np.float16(1.0)),
+        variant(plain, "data_1d.npz", data=np.zeros(7, np.float16)),
+        variant(plain, "data_4d.npz", data=np.zeros((tree.capacity, 2, 2, 2), np.float16)),
+        variant(plain, "offset_short.npz", offset=np.zeros(2, np.float32)),
+        variant(plain, "offset_0d.npz", offset=np.float32(0.5)),
+        variant(plain, "invradius3_short.npz", invradius3=np.zeros(1, np.float32)),
+        variant(plain, "child_3d.npz", child=np.zeros((tree.capacity, 2, 2), np.int32)),
+        variant(quant, "qm_1d.npz", quant_map=zq["quant_map"].reshape(-1)),
+        variant(quant, "qm_0d.npz", quant_map=np.uint16(3)),
+        variant(quant, "qc_0d.npz", quant_colors=np.float16(0.5)),
+        variant(quant, "qc_2d.npz", quant_colors=zq["quant_colors"].reshape(-1, 3)),
+        variant(quant, "ret_0d.npz", data_retained=np.float16(0.25)),
+        variant(quant, "ret_2d.npz", data_retained=zq["data_retained"].reshape(-1, 3)),
+        variant(quant, "sigma_0d.npz", sigma=np.float16(2.0)),
+    ]
+    for ok in (plain, quant):
+        r = subprocess.run([asan_exe, "tree", ok], capture_output=True, env=env, timeout=120)
+        assert r.returncode == 0, r.stderr.decode("latin1")[-500:]
+    for p in cases:
+        r = subprocess.run([asan_exe, "tree", p], capture_output=True, env=env, timeout=120)
+        err = r.stderr.decode("latin1")
+        assert r.returncode > 0, f"{os.path.basename(p)} was accepted (rc {r.returncode})"
+        assert "AddressSanitizer" not in err and "runtime error" not in err, \
+            os.path.basename(p) + ": " + err[-1500:]

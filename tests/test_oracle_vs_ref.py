@@ -80,18 +80,32 @@ def test_compositing_over_existing_frame():
     assert np.array_equal(rgba_o, rgba_r)
 
 
-def test_probe_overlay():
-    tree = common.small_scene(depth=5, basis_dim=4, seed=181)
+@pytest.mark.parametrize("fmt,bd,minmax,offscreen", [
+    ("SH", 4, (0, 3), True), ("SH", 16, (2, 11), True), ("SH", 25, (0, 24), True),
+    ("SG", 9, (0, 8), True), ("ASG", 4, (0, 3), False), ("RGBA", 0, (0, 24), True)])
+def test_probe_overlay(fmt, bd, minmax, offscreen):
+    tree = common.small_scene(depth=5, basis_dim=bd, fmt=fmt, seed=181)
     tr, w, h, f = common.camera_for(pose_idx=5, size=72)
     th = ob.TreeHandle(tree)
     cam = ob.make_camera(tr, w, h, f)
     # basis_minmax narrowed to the coefficients that exist (what VolumeRenderer::set does,
     # src/cuda_renderer.cpp:176-177); upstream reads out of bounds otherwise
     opt = ob.default_options(enable_probe=1, probe=(0.1, 0.0, 0.2), probe_disp_size=30,
-                             basis_minmax=(0, 3))
-    rgba_o, _, _ = ob.render(th, cam, opt)
-    rgba_r = ob.ref_render(th, cam, opt)
+                             basis_minmax=minmax)
+    kw = {}
+    if not offscreen:
+        rng = np.random.default_rng(8)
+        kw = dict(offscreen=False, rgba_init=rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8),
+                  depth_init=rng.uniform(2.0, 6.0, size=(h, w)).astype(np.float32))
+    rgba_o, _, _ = ob.render(th, cam, opt, **kw)
+    rgba_r = ob.ref_render(th, cam, opt, **kw)
     assert np.array_equal(rgba_o, rgba_r)
+    # probe coefficients: retrieve_cursor_lumisphere_kernel (volrend.cu:175-191)
+    n = tree.data_dim - 1
+    a, b = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    ob.lib().or_probe_coeffs(C.byref(th.struct), C.byref(opt), a.ctypes.data)
+    ob.ref_lib().ref_probe_coeffs(C.byref(th.struct), C.byref(opt), b.ctypes.data)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
 def test_point_query_and_basis():

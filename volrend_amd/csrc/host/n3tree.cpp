@@ -145,6 +145,7 @@ void N3Tree::load_npz(internal::NpzFile& npz) {
 
     if (npz.count("invradius3")) {
         const internal::NpyArray& a = npz["invradius3"];
+        if (a.num_vals < 3) throw std::runtime_error("invradius3 must hold 3 values");
         for (int i = 0; i < 3; ++i) scale[i] = (float)a.as_double(i);
     } else {
         scale[0] = scale[1] = scale[2] = (float)need("invradius").as_double();
@@ -152,6 +153,7 @@ void N3Tree::load_npz(internal::NpzFile& npz) {
     printf("INFO: Scale %f %f %f\n", scale[0], scale[1], scale[2]);
     {
         const internal::NpyArray& a = need("offset");
+        if (a.num_vals < 3) throw std::runtime_error("offset must hold 3 values");
         for (int i = 0; i < 3; ++i) offset[i] = (float)a.as_double(i);
     }
 
@@ -173,12 +175,15 @@ void N3Tree::load_npz(internal::NpzFile& npz) {
         const internal::NpyArray& qc = npz["quant_colors"];
         if (qc.word_size != 2) throw std::runtime_error("codebook must be stored in half precision");
         const internal::NpyArray& qm = need("quant_map");
+        // ranks first: nothing below may index a shape that is not there
+        if (qm.shape.size() != 5 || qc.shape.size() != 3 || qc.shape[1] != 65536 ||
+            qc.shape[2] != 3)
+            throw std::runtime_error("quant_map / quant_colors have unexpected shapes");
+        if (qm.shape[1] == 0 || qm.shape[1] > 0x7FFFFFFFu)
+            throw std::runtime_error("quant_map capacity out of range");
         capacity = (int)qm.shape[1];
         const size_t n_q = qm.shape[0];
         if (qc.shape[0] != n_q) throw std::runtime_error("codebook and map basis numbers does not match");
-        if ((int)qm.shape.size() != 5 || qc.shape.size() != 3 || qc.shape[1] != 65536 ||
-            qc.shape[2] != 3)
-            throw std::runtime_error("quant_map / quant_colors have unexpected shapes");
         need("sigma");
         quant_colors_ = std::move(npz["quant_colors"]);
         quant_map_ = std::move(npz["quant_map"]);
@@ -188,6 +193,8 @@ void N3Tree::load_npz(internal::NpzFile& npz) {
         if (sigma_.word_size != 2 || quant_map_.word_size != 2 ||
             (!data_retained_.empty() && data_retained_.word_size != 2))
             throw std::runtime_error("quantised arrays must be 16-bit");
+        if (!data_retained_.empty() && data_retained_.shape.size() != 6)
+            throw std::runtime_error("data_retained must be [n_retained, capacity, N, N, N, 3]");
         data_ = internal::NpyArray();
         {  // every codebook array is indexed per slot: check before anything reads them
             const size_t n_slots = (size_t)capacity * N3_;
@@ -202,6 +209,8 @@ void N3Tree::load_npz(internal::NpzFile& npz) {
         if (!(device_decode && upload_on_open)) decode_quantized_host();
     } else {
         internal::NpyArray& d = need("data");
+        if (d.shape.size() != 5 || d.shape[0] == 0 || d.shape[0] > 0x7FFFFFFFu)
+            throw std::runtime_error("data must be float16 [capacity, N, N, N, data_dim]");
         capacity = (int)d.shape[0];
         if (d.word_size != 2) throw std::runtime_error("data must be stored in half precision");
         data_ = std::move(d);
