@@ -28,6 +28,18 @@
  * The library owns device copies of trees; callers own output buffers,
  * streams and events.  One host thread per device, or one thread driving
  * several devices with explicit vr_set_device().
+ *
+ * Launches in flight.  Unlike the reference's launch_renderer, a launch here
+ * carries per-launch scratch in device memory (frame table, ray queue, ray
+ * buffer, probe coefficients).  The library keeps a ring of 8 such launch
+ * slots per tree; each slot remembers the last launch that used it with an
+ * event, and a later launch that lands on the slot makes ITS stream wait for
+ * that event (a device-side wait -- the host never blocks).  So any number of
+ * launches on any number of streams and host threads is safe; more than 8
+ * un-finished launches of one tree simply serialise.  The one host-blocking
+ * step is the (re)allocation of a slot's ray buffer the first time a slot sees
+ * a batch larger than any before -- call vr_reserve() once to take that out of
+ * the render loop.
  */
 #ifndef VOLREND_HIP_H_
 #define VOLREND_HIP_H_
@@ -39,7 +51,7 @@
 extern "C" {
 #endif
 
-#define VR_ABI_VERSION 1
+#define VR_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------ */
 enum {
@@ -206,9 +218,18 @@ int vr_render(vr_tree_t tree, const VrCamera* cam, const VrRenderOptions* opt,
  * known up front): cams[i] -> frames[i].  All entries must share image size,
  * intrinsics, layout, sharding and fp_mode; only the pose and the buffers differ.
  * A single 800x800 frame cannot fill 256 CUs; a batch can.  1 <= n <= VR_MAX_BATCH. */
-#define VR_MAX_BATCH 128
+#define VR_MAX_BATCH 512
 int vr_render_batch(vr_tree_t tree, int n_frames, const VrCamera* cams,
                     const VrRenderOptions* opt, const VrFrame* frames, void* stream);
+/* Pre-allocates the ray buffers of every launch slot for batches of up to n_frames whole
+ * width x height frames, so that no later vr_render / vr_render_batch of that size (or
+ * smaller, or tile-sharded) allocates or blocks.  Optional; synchronous. */
+int vr_reserve(vr_tree_t tree, int width, int height, int n_frames);
+/* Sticky device status word of the tree's launches: bit 0 = some ray hit the 2^22-sample
+ * guard (the reference would still be looping).  Synchronous; reset != 0 clears it.
+ * vr_render* refuses step_size <= 0 / NaN (VR_ERR_INVALID_ARGUMENT), where the reference
+ * hangs, so the bit only ever fires on pathological step_size / scene combinations. */
+int vr_tree_status(vr_tree_t tree, uint32_t* status, int reset);
 /* Scheduling knobs of the persistent kernel ("march_max", "refill_min",
  * "waves_per_cu"); results never depend on them. */
 int vr_set_tuning(const char* key, int value);

@@ -44,7 +44,7 @@ def test_every_header_symbol_is_exported(lib_path):
 def test_ctypes_prototypes_cover_the_header(lib_path):
     assert sorted(_abi.PROTOTYPES) == header_functions()
     L = _abi.lib()  # resolves every symbol; raises AttributeError otherwise
-    assert L.vr_abi_version() == 1
+    assert L.vr_abi_version() == _abi.ABI_VERSION == 2
 
 
 def test_struct_layouts_match_the_c_compiler():

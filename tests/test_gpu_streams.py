@@ -1,0 +1,80 @@
+"""-m gpu: launches in flight on several streams (the launch-slot ring of vr_api.cpp).
+
+Every launch carries per-launch scratch in device memory; a slot is reused only behind the
+event of the launch that held it last.  3 streams x 6 launches (> 8 slots, different poses and
+image sizes, probe on some) must all reproduce the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    return torch
+
+
+def test_three_streams_six_launches_each(torch_cuda):
+    torch = torch_cuda
+    from volrend_amd import api
+    tree = common.small_scene(depth=6, basis_dim=9, seed=931)
+    t = api.N3Tree.from_synth(tree)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    jobs = []
+    for j in range(18):
+        size = [96, 64, 120][j % 3] + 8 * (j // 6)
+        tr, w, h, f = common.camera_for(pose_idx=j % 8, size=size)
+        kw = {}
+        if j % 4 == 1:
+            kw = dict(enable_probe=True, probe=(0.05 * j - 0.3, 0.1, 0.2), probe_disp_size=24,
+                      basis_minmax=(0, 8))
+        n = 1 + (j % 3)  # batch of n identical poses: every frame must equal the oracle's
+        imgs = torch.zeros((n, h, w, 4), dtype=torch.uint8, device="cuda")
+        jobs.append((tr, w, h, f, kw, n, imgs))
+    torch.cuda.synchronize()
+    for rnd in range(6):          # round-robin: launch j of stream s is job 3*rnd + s
+        for si, st in enumerate(streams):
+            tr, w, h, f, kw, n, imgs = jobs[3 * rnd + si]
+            cam = api.Camera(w, h, f, f)
+            with torch.cuda.stream(st):
+                api.launch_renderer_batch(t, cam, [tr] * n, api.RenderOptions(**kw), list(imgs),
+                                          st, True)
+    torch.cuda.synchronize()
+    for j, (tr, w, h, f, kw, n, imgs) in enumerate(jobs):
+        okw = {k: (1 if v is True else v) for k, v in kw.items()}
+        rgba_o, _, _ = common.oracle_frame(tree, tr, w, h, f, 0, **okw)
+        got = imgs.cpu().numpy()
+        for i in range(n):
+            assert np.array_equal(got[i], rgba_o), f"job {j} frame {i}"
+    t.free_device()
+
+
+def test_reserve_status_and_step_size(torch_cuda):
+    torch = torch_cuda
+    from volrend_amd import _abi, api
+    tree = common.small_scene(depth=4, basis_dim=4, seed=933)
+    t = api.N3Tree.from_synth(tree)
+    t.reserve(200, 120, 6)
+    with pytest.raises(_abi.VolrendError):
+        t.reserve(200, 120, _abi.MAX_BATCH + 1)
+    tr, w, h, f = common.camera_for(pose_idx=2, size=64)
+    cam = api.Camera(w, h, f, f)
+    cam.transform = np.asarray(tr, np.float32)
+    img = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    for bad in (0.0, -1e-3, float("nan")):
+        with pytest.raises(_abi.VolrendError) as e:
+            api.launch_renderer(t, cam, api.RenderOptions(step_size=bad), img, None, None, True)
+        assert e.value.code == 1 and "step_size" in str(e.value)
+    api.launch_renderer(t, cam, api.RenderOptions(), img, None, None, True)
+    torch.cuda.synchronize()
+    assert t.status() == 0
+    rgba_o, _, _ = common.oracle_frame(tree, tr, w, h, f, 0)
+    assert np.array_equal(img.cpu().numpy(), rgba_o)
+    t.free_device()

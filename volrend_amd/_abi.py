@@ -61,6 +61,9 @@ class VrFrame(C.Structure):
                 ("counters", C.c_void_p)]
 
 
+ABI_VERSION = 2  # VR_ABI_VERSION of include/volrend_hip.h
+MAX_BATCH = 512  # VR_MAX_BATCH
+
 COUNTER_FIELDS = ("rays", "rays_hit_box", "samples", "child_reads", "hit_samples", "alg_bytes",
                   "early_stops")
 
@@ -86,6 +89,8 @@ PROTOTYPES = {
                             C.POINTER(VrFrame), C.c_void_p]),
     "vr_render_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(VrCamera),
                                   C.POINTER(VrRenderOptions), C.POINTER(VrFrame), C.c_void_p]),
+    "vr_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "vr_tree_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "vr_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "vr_sched_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 8), C.c_int]),
     "vr_assemble_tiles": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -120,7 +125,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if L.vr_abi_version() != 1:
+        if L.vr_abi_version() != ABI_VERSION:
             raise RuntimeError("libvolrend_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -308,6 +308,17 @@ class N3Tree:
                  "retire_rounds", "retired", "iterations")
         return dict(zip(names, [int(v) for v in out]))
 
+    def reserve(self, width: int, height: int, n_frames: int) -> None:
+        """Pre-allocate the per-launch ray buffers (vr_reserve): no later launch of that
+        size blocks or allocates."""
+        _abi.check(_abi.lib().vr_reserve(self.handle, int(width), int(height), int(n_frames)))
+
+    def status(self, reset: bool = False) -> int:
+        """Sticky device status word (vr_tree_status): bit 0 = a ray hit the sample guard."""
+        out = C.c_uint32(0)
+        _abi.check(_abi.lib().vr_tree_status(self.handle, C.byref(out), 1 if reset else 0))
+        return int(out.value)
+
     def info(self) -> dict:
         i = _abi.VrTreeInfo()
         _abi.check(_abi.lib().vr_tree_info(self._handle, C.byref(i)))

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -64,8 +65,20 @@ Tuning& tuning() {
 
 }  // namespace
 
-constexpr unsigned kLaunchSlots = 4;
+constexpr unsigned kLaunchSlots = 8;
 constexpr unsigned kSlotWords = 160;  // [0] ray count, [16 + 16*x] queue head x (x < 8)
+
+// Per-launch scratch that a kernel reads while it runs: frame table, queue heads, ray count,
+// ray buffer, probe coefficients.  A launch takes the next slot of a ring; `done` is recorded
+// on the launch's stream behind its last kernel and the next user of the slot makes ITS stream
+// wait for it (device-side wait, the host never blocks), so any number of launches on any
+// number of streams may be in flight -- beyond kLaunchSlots they simply serialise.
+struct LaunchSlot {
+    hipEvent_t done = nullptr;
+    bool used = false;          // `done` has been recorded at least once
+    uint32_t* rays = nullptr;   // ray buffer, grown on demand (or up front by vr_reserve)
+    size_t ray_bytes = 0;
+};
 
 struct VrTreeOpaque {
     int device = 0;
@@ -77,14 +90,12 @@ struct VrTreeOpaque {
     float* extra = nullptr;
     uint32_t* status = nullptr;
     unsigned long long* sched_stats = nullptr;  // 8 x u64, see vr_sched_stats
-    float* probe_buf = nullptr;  // data_dim floats: the lumisphere at opt.probe
-    // Launch slots: every launch takes the next slot of a ring for its per-frame table
-    // and ray-queue head, so up to kLaunchSlots launches may be in flight (any streams).
-    vr::FrameDesc* slot_frames = nullptr;
-    uint32_t* slot_heads = nullptr;      // per slot: [0] queue head, [1] ray count
-    uint32_t* slot_rays[kLaunchSlots] = {};   // per slot: ray buffer, grown on demand
-    size_t slot_ray_bytes[kLaunchSlots] = {};
-    std::atomic<unsigned> launch_seq{0};
+    float* probe_buf = nullptr;  // kLaunchSlots x data_dim floats: the lumisphere at opt.probe
+    vr::FrameDesc* slot_frames = nullptr;  // kLaunchSlots x kMaxBatch
+    uint32_t* slot_heads = nullptr;        // kLaunchSlots x kSlotWords
+    LaunchSlot slots[kLaunchSlots];
+    unsigned launch_seq = 0;
+    std::mutex launch_mutex;  // slot bookkeeping + enqueue order of one launch
     int n_cus = 256;
     VrTreeDesc desc{};  // pointers cleared; scalars kept
     int32_t max_depth = 0;
@@ -175,6 +186,17 @@ float host_norm3(const float* d, int fma) {
     return std::sqrt(s);
 }
 
+// basis words kept per ray in the ray buffer: what the kernel flavour for this basis_dim reads
+int basis_words_of(const VrTreeOpaque* t) {
+    const int bd = t->desc.basis_dim;
+    if (t->desc.format == VR_FORMAT_RGBA || bd < 0) return 0;
+    return (bd == 4 || bd == 9 || bd == 16 || bd == 25) ? bd : 1;
+}
+
+size_t ray_buffer_bytes(uint32_t total_rays, int basis_words) {
+    return (size_t)total_rays * (15 + (size_t)basis_words) * sizeof(uint32_t);
+}
+
 void fill_tree_params(vr::KParams& k, const VrTreeOpaque* t) {
     k.nodes = t->nodes;
     k.leaves = t->leaves;
@@ -187,6 +209,7 @@ void fill_tree_params(vr::KParams& k, const VrTreeOpaque* t) {
     }
     k.N = t->desc.N;
     k.N3 = t->desc.N * t->desc.N * t->desc.N;
+    k.capacity = t->desc.capacity;
     k.data_dim = t->desc.data_dim;
     k.format = t->desc.format;
     k.basis_dim = t->desc.basis_dim;
@@ -373,7 +396,10 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     if (e == hipSuccess) e = hipMemset(t->status, 0, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&t->sched_stats, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(t->sched_stats, 0, 8 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void**)&t->probe_buf, sizeof(float) * (size_t)d->data_dim);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&t->probe_buf, sizeof(float) * (size_t)d->data_dim * kLaunchSlots);
+    for (unsigned i = 0; i < kLaunchSlots && e == hipSuccess; ++i)
+        e = hipEventCreateWithFlags(&t->slots[i].done, hipEventDisableTiming);
     if (e == hipSuccess)
         e = hipMalloc((void**)&t->slot_frames, sizeof(vr::FrameDesc) * vr::kMaxBatch * kLaunchSlots);
     if (e == hipSuccess)
@@ -471,8 +497,10 @@ int vr_tree_free(vr_tree_t t) {
     if (t->probe_buf) (void)hipFree(t->probe_buf);
     if (t->slot_frames) (void)hipFree(t->slot_frames);
     if (t->slot_heads) (void)hipFree(t->slot_heads);
-    for (unsigned i = 0; i < kLaunchSlots; ++i)
-        if (t->slot_rays[i]) (void)hipFree(t->slot_rays[i]);
+    for (unsigned i = 0; i < kLaunchSlots; ++i) {
+        if (t->slots[i].rays) (void)hipFree(t->slots[i].rays);
+        if (t->slots[i].done) (void)hipEventDestroy(t->slots[i].done);
+    }
     delete t;
     return VR_OK;
 }
@@ -605,6 +633,12 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
         instrumented = instrumented || fi.counters != nullptr;
     }
 
+    // the reference spins forever on step_size <= 0 (rt_core.cuh:108-175: t never advances past
+    // a leaf face); the kernel's iteration cap would cut such rays short silently -- refuse.
+    if (!(opt->step_size > 0.f))
+        return fail(VR_ERR_INVALID_ARGUMENT, "step_size must be positive (got %g)",
+                    (double)opt->step_size);
+
     vr::KParams k;
     memset(&k, 0, sizeof(k));
     fill_tree_params(k, t);
@@ -622,9 +656,6 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.render_depth = opt->render_depth != 0;
     k.enable_probe = opt->enable_probe != 0;
     k.probe_disp_size = opt->probe_disp_size;
-    k.probe_coeffs = t->probe_buf;
-    if (k.enable_probe)  // launch_renderer's pre-kernel, volrend.cu:202-209
-        HIP_TRY(vr::launch_probe(k, opt->probe, t->probe_buf, static_cast<hipStream_t>(stream)));
 
     // rodrigues (reference src/cuda/volrend.cu:57-71): angle/axis/cos/sin are
     // uniform over the frame -> once here, with the oracle's rounding sequence
@@ -663,32 +694,40 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.refill_min = tn.refill_min;
     k.shade_min = tn.shade_min;
     k.frame_minor = tn.frame_minor;
-    // launch slot: frame table + queue head in device memory (ring, see VrTreeOpaque)
-    const unsigned slot = t->launch_seq.fetch_add(1) % kLaunchSlots;
+    // launch slot: per-launch scratch in device memory (ring, see LaunchSlot)
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> guard(t->launch_mutex);
+    const unsigned slot = t->launch_seq++ % kLaunchSlots;
+    LaunchSlot& ls = t->slots[slot];
     k.frames = t->slot_frames + (size_t)slot * vr::kMaxBatch;
     k.queue_head = t->slot_heads + kSlotWords * slot + 16;
     k.ray_count_rw = t->slot_heads + kSlotWords * slot;
     k.n_queues = tn.xcd_queues ? 8 : 1;
     k.chunk_max = tn.chunk_max;
     k.ray_count = k.ray_count_rw;
-    // basis words kept per ray: what the kernel flavour for this basis_dim reads
-    const int bd = t->desc.basis_dim;
-    k.basis_words = (t->desc.format == VR_FORMAT_RGBA || bd < 0)
-                        ? 0
-                        : ((bd == 4 || bd == 9 || bd == 16 || bd == 25) ? bd : 1);
-    const size_t need = (size_t)k.total_rays * (15 + (size_t)k.basis_words) * sizeof(uint32_t);
-    if (t->slot_ray_bytes[slot] < need) {  // first use of the slot / larger batch: (re)allocate
-        if (t->slot_rays[slot]) {
-            HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipFree(t->slot_rays[slot]));
-            t->slot_rays[slot] = nullptr;
-            t->slot_ray_bytes[slot] = 0;
+    k.basis_words = basis_words_of(t);
+    const size_t need = ray_buffer_bytes(k.total_rays, k.basis_words);
+    if (ls.ray_bytes < need) {
+        // First use of the slot, or a larger batch than any before: (re)allocate.  This is the
+        // one place where an enqueue-only call may block -- on THIS slot's previous launch
+        // only, and hipFree/hipMalloc may synchronise the device; vr_reserve() moves it out of
+        // the render loop.
+        if (ls.rays) {
+            if (ls.used) HIP_TRY(hipEventSynchronize(ls.done));
+            HIP_TRY(hipFree(ls.rays));
+            ls.rays = nullptr;
+            ls.ray_bytes = 0;
         }
-        HIP_TRY(hipMalloc((void**)&t->slot_rays[slot], need));
-        t->slot_ray_bytes[slot] = need;
+        HIP_TRY(hipMalloc((void**)&ls.rays, need));
+        ls.ray_bytes = need;
     }
-    k.ray_buf_rw = t->slot_rays[slot];
+    k.ray_buf_rw = ls.rays;
     k.ray_buf = k.ray_buf_rw;
+    // whoever used this slot last (any stream) must have finished before its scratch is rewritten
+    if (ls.used) HIP_TRY(hipStreamWaitEvent(hs, ls.done, 0));
+    k.probe_coeffs = t->probe_buf + (size_t)slot * (size_t)t->desc.data_dim;
+    if (k.enable_probe)  // launch_renderer's pre-kernel, volrend.cu:202-209
+        HIP_TRY(vr::launch_probe(k, opt->probe, const_cast<float*>(k.probe_coeffs), hs));
 
     // frame table -> device memory, kTableChunk poses per (tiny) kernel
     for (int first = 0; first < n_frames; first += vr::kTableChunk) {
@@ -703,10 +742,46 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
             tbl.f[i].depth = frames[first + i].depth;
             tbl.f[i].counters = reinterpret_cast<unsigned long long*>(frames[first + i].counters);
         }
-        HIP_TRY(vr::launch_prepare(k, tbl, static_cast<hipStream_t>(stream)));
+        HIP_TRY(vr::launch_prepare(k, tbl, hs));
     }
-    HIP_TRY(vr::launch_render(k, f->fp_mode, t->n_cus * tn.waves_per_cu,
-                              static_cast<hipStream_t>(stream)));
+    HIP_TRY(vr::launch_render(k, f->fp_mode, t->n_cus * tn.waves_per_cu, hs));
+    HIP_TRY(hipEventRecord(ls.done, hs));
+    ls.used = true;
+    return VR_OK;
+}
+
+int vr_reserve(vr_tree_t t, int width, int height, int n_frames) {
+    if (!t) return fail(VR_ERR_INVALID_ARGUMENT, "tree is NULL");
+    if (width < 1 || height < 1 || width > 65535 || height > 65535 || n_frames < 1 ||
+        n_frames > VR_MAX_BATCH)
+        return fail(VR_ERR_INVALID_ARGUMENT, "vr_reserve(%d x %d, %d frames) out of range", width,
+                    height, n_frames);
+    // whole frames (world = 1), rounded up to 8x8 wave blocks like tile_geometry does
+    const int64_t total = (int64_t)((width + 7) / 8) * ((height + 7) / 8) * 64 * n_frames;
+    if (total >= (1ll << 32))
+        return fail(VR_ERR_INVALID_ARGUMENT, "batch of %lld rays exceeds the 32-bit ray queue",
+                    (long long)total);
+    const size_t need = ray_buffer_bytes((uint32_t)total, basis_words_of(t));
+    std::lock_guard<std::mutex> guard(t->launch_mutex);
+    for (unsigned i = 0; i < kLaunchSlots; ++i) {
+        LaunchSlot& ls = t->slots[i];
+        if (ls.ray_bytes >= need) continue;
+        if (ls.rays) {
+            if (ls.used) HIP_TRY(hipEventSynchronize(ls.done));
+            HIP_TRY(hipFree(ls.rays));
+            ls.rays = nullptr;
+            ls.ray_bytes = 0;
+        }
+        HIP_TRY(hipMalloc((void**)&ls.rays, need));
+        ls.ray_bytes = need;
+    }
+    return VR_OK;
+}
+
+int vr_tree_status(vr_tree_t t, uint32_t* status, int reset) {
+    if (!t || !status) return fail(VR_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipMemcpy(status, t->status, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(t->status, 0, sizeof(uint32_t)));
     return VR_OK;
 }
 

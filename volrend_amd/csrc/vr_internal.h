@@ -8,7 +8,7 @@
 
 namespace vr {
 
-constexpr int kMaxBatch = 128;   // frames per launch (VR_MAX_BATCH)
+constexpr int kMaxBatch = 512;   // frames per launch (VR_MAX_BATCH)
 constexpr int kTableChunk = 48;  // frames per prepare_launch_kernel call (4 KB kernarg limit)
 
 // Per-frame part of a launch: pose and buffers.  Lives in device memory (one
@@ -40,6 +40,7 @@ struct KParams {
     float offset[3];
     float scale[3];
     int32_t N, N3;
+    int64_t capacity;         // nodes
     int32_t data_dim;
     int32_t format;
     int32_t basis_dim;

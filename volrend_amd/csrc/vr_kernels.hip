@@ -1304,11 +1304,14 @@ __global__ void relayout_nodes_kernel(const int32_t* child, const uint16_t* data
     const int64_t n = i / N3;
     const int s = (int)(i - n * N3);
     const int32_t skip = child[i];
+    const int64_t target = n + skip;
     uint32_t w;
-    if (skip == 0) {
+    // Links of nodes the root cannot reach are not covered by the host's topology check
+    // (file capacity > used nodes): a link that leaves the array becomes a leaf word.
+    if (skip == 0 || target <= 0 || target >= n_slots / N3) {
         w = kLeafBit | (uint32_t)data[i * data_dim + (data_dim - 1)];
     } else {
-        w = (uint32_t)perm[n + skip];
+        w = (uint32_t)perm[target];
     }
     nodes[(int64_t)perm[n] * N3 + s] = w;
 }
@@ -1419,7 +1422,8 @@ hipError_t launch_basis(const KParams& p, dim3 grid, dim3 block, hipStream_t s) 
 
 template <int FMA>
 hipError_t launch_fp(const KParams& p, dim3 grid, dim3 block, hipStream_t s) {
-    const bool n2 = (p.N == 2) && p.max_depth <= 23;
+    // query_n2 forms node*8+slot and its byte offset in 32 bits: capacity < 2^27
+    const bool n2 = (p.N == 2) && p.max_depth <= 23 && p.capacity < (1ll << 27);
     const bool lobes = p.format == VR_FORMAT_SG || p.format == VR_FORMAT_ASG;
     if (!n2) return launch_basis<FMA, MODE_GENERIC>(p, grid, block, s);
     if (lobes || p.instrumented) return launch_basis<FMA, MODE_FULL>(p, grid, block, s);
