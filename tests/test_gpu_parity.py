@@ -302,3 +302,40 @@ def test_random_configurations_bit_exact(torch_cuda, fp_mode):
             assert_parity(rgba_g, acc_g, rgba_o, acc_o)
         except AssertionError as e:
             raise AssertionError(f"seed {seed} {what} {kw}: {e}") from None
+
+
+@pytest.mark.parametrize("fp_mode", [0, 1])
+@pytest.mark.parametrize("top_levels,brick_levels", [(1, 1), (1, 3), (2, 2), (2, 3), (3, 3), (4, 1),
+                                                     (5, 2), (6, 3), (8, 3)])
+def test_lookup_structure_geometries(torch_cuda, top_levels, brick_levels, fp_mode):
+    """The N == 2 lookup structure (top grid of 2^G0 cells per axis + bricks of 2^BL entries per
+    axis + child words below, vr_kernels.hip) is a pure index: whatever its geometry, every
+    sample must land in the leaf the reference's root descent finds (n3tree_query.hpp:13-48).
+    Small geometries push a depth-7 tree through every branch: top leaves, brick leaves of all
+    three depths, and the child-word walk below the bricks."""
+    from volrend_amd import api
+    tree = common.small_scene(depth=7, basis_dim=4, seed=1201)
+    tr, w, h, f = common.camera_for(pose_idx=3, size=72)
+    rgba_o, acc_o, cnt = common.oracle_frame(tree, tr, w, h, f, fp_mode)
+    assert cnt["hit_samples"] > 1000
+    api.set_tuning(top_levels=top_levels, brick_levels=brick_levels)
+    try:
+        rgba_g, acc_g = gpu_frame(torch_cuda, tree, tr, w, h, f, fp_mode)
+        # instrumented flavour: child_reads = sum of leaf depths must match the oracle's walk
+        import torch
+        t = api.N3Tree.from_synth(tree)
+        cam = api.Camera(w, h, f, f)
+        cam.transform = np.asarray(tr, np.float32)
+        img = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        counters = torch.zeros(7, dtype=torch.int64, device="cuda")
+        api.launch_renderer(t, cam, api.RenderOptions(), img, None, None, True, counters=counters,
+                            fp_mode=fp_mode)
+        torch.cuda.synchronize()
+        from volrend_amd import _abi
+        cnt_g = dict(zip(_abi.COUNTER_FIELDS, [int(v) for v in counters.cpu().tolist()]))
+        t.free_device()
+    finally:
+        api.set_tuning(top_levels=6, brick_levels=3)
+    assert_parity(rgba_g, acc_g, rgba_o, acc_o)
+    assert cnt_g == cnt
+    assert np.array_equal(img.cpu().numpy(), rgba_o)

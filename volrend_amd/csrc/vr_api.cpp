@@ -38,6 +38,8 @@ struct Tuning {
     int frame_minor = 1;
     int xcd_queues = 1;
     int chunk_max = 4096;
+    int top_levels = 6;    // lookup structure of trees uploaded from now on (vr_kernels.hip)
+    int brick_levels = 3;
 };
 Tuning& tuning() {
     static Tuning tn = [] {
@@ -49,6 +51,8 @@ Tuning& tuning() {
         if (const char* e = getenv("VR_FRAME_MINOR")) x.frame_minor = atoi(e) != 0;
         if (const char* e = getenv("VR_XCD_QUEUES")) x.xcd_queues = atoi(e) != 0;
         if (const char* e = getenv("VR_CHUNK_MAX")) x.chunk_max = atoi(e) < 64 ? 64 : (atoi(e) & ~63);
+        if (const char* e = getenv("VR_TOP_LEVELS")) x.top_levels = atoi(e);
+        if (const char* e = getenv("VR_BRICK_LEVELS")) x.brick_levels = atoi(e);
         return x;
     }();
     return tn;
@@ -84,8 +88,9 @@ struct VrTreeOpaque {
     int device = 0;
     uint32_t* nodes = nullptr;   // device layout (vr_kernels.hip)
     uint16_t* leaves = nullptr;
-    uint32_t* grid = nullptr;
-    int grid_levels = 0;
+    uint2* top = nullptr;        // lookup structure (N == 2), see vr_kernels.hip
+    uint32_t* bricks = nullptr;
+    int top_levels = 0, brick_levels = 0, n_bricks = 0;
     int leaf_stride_h = 0;
     float* extra = nullptr;
     uint32_t* status = nullptr;
@@ -108,12 +113,16 @@ namespace {
 // not been reached before (a tree, not a DAG / cycle), inside [1, capacity).
 // Returns the deepest leaf level or -1.  A malformed file would otherwise make
 // the device descent loop forever.
-int validate_topology(const int32_t* child, int64_t cap, int N3, char* why, size_t why_len) {
+// level[n] = depth of node n (root 0), 255 = not reachable from the root.
+int validate_topology(const int32_t* child, int64_t cap, int N3, std::vector<uint8_t>& level,
+                      char* why, size_t why_len) {
     if (cap <= 0) {
         snprintf(why, why_len, "capacity must be positive");
         return -1;
     }
     std::vector<uint8_t> seen((size_t)cap, 0);
+    level.assign((size_t)cap, 255);
+    level[0] = 0;
     std::vector<int64_t> cur{0}, next;
     seen[0] = 1;
     int depth = 0;
@@ -135,6 +144,7 @@ int validate_topology(const int32_t* child, int64_t cap, int N3, char* why, size
                     return -1;
                 }
                 seen[(size_t)m] = 1;
+                level[(size_t)m] = (uint8_t)(depth + 1);
                 next.push_back(m);
             }
         }
@@ -148,23 +158,48 @@ int validate_topology(const int32_t* child, int64_t cap, int N3, char* why, size
     return depth;
 }
 
-// New node numbering: pre-order depth-first from the root (children in slot order),
-// unreachable nodes keep their relative order behind the reachable ones.  "file" keeps
-// the numbering of the file (VR_NODE_ORDER=file, for A/B measurements).
-std::vector<int32_t> node_permutation(const int32_t* child, int64_t cap, int N3) {
+// New node numbering: pre-order depth-first from the root (children in slot order), so a
+// subtree is one contiguous run of the arrays.  Exception for the lookup structure (N == 2,
+// G0 > 0): behind an internal node of level G0 (a brick root) come first ALL its descendants of
+// the next BL - 1 levels, breadth-first (<= 8 + 64 nodes: a brick entry names the parent of its
+// leaf as root + delta), and only then the subtrees hanging below level G0 + BL - 1, each
+// depth-first.  Unreachable nodes keep their relative order behind the reachable ones.
+// brick_roots receives the new indices of the level-G0 internal nodes (ascending).
+std::vector<int32_t> node_permutation(const int32_t* child, int64_t cap, int N3, int G0, int BL,
+                                      const std::vector<uint8_t>& level,
+                                      std::vector<int32_t>& brick_roots) {
     std::vector<int32_t> perm((size_t)cap, -1);
-    const char* env = getenv("VR_NODE_ORDER");
-    if (env && !strcmp(env, "file")) {
-        for (int64_t i = 0; i < cap; ++i) perm[(size_t)i] = (int32_t)i;
-        return perm;
-    }
+    brick_roots.clear();
     int32_t next = 0;
-    std::vector<int64_t> stack{0};
+    std::vector<int64_t> stack{0}, ring, ring_next;
     while (!stack.empty()) {
         const int64_t n = stack.back();
         stack.pop_back();
         perm[(size_t)n] = next++;
         const int32_t* c = child + n * N3;
+        if (G0 > 0 && level[(size_t)n] == G0) {
+            brick_roots.push_back(perm[(size_t)n]);
+            // levels G0+1 .. G0+BL-1 breadth-first right behind the root
+            ring.assign(1, n);
+            for (int k = 1; k < BL; ++k) {
+                ring_next.clear();
+                for (int64_t m : ring)
+                    for (int s = 0; s < N3; ++s)
+                        if (child[m * N3 + s] != 0) {
+                            const int64_t ch = m + child[m * N3 + s];
+                            perm[(size_t)ch] = next++;
+                            ring_next.push_back(ch);
+                        }
+                ring.swap(ring_next);
+            }
+            // `ring` = the nodes of level G0+BL-1: their children start ordinary subtrees
+            for (size_t i = ring.size(); i-- > 0;) {
+                const int64_t m = ring[i];
+                for (int s = N3 - 1; s >= 0; --s)
+                    if (child[m * N3 + s] != 0) stack.push_back(m + child[m * N3 + s]);
+            }
+            continue;
+        }
         for (int s = N3 - 1; s >= 0; --s)  // reversed: slot 0 is visited first
             if (c[s] != 0) stack.push_back(n + c[s]);
     }
@@ -200,8 +235,10 @@ size_t ray_buffer_bytes(uint32_t total_rays, int basis_words) {
 void fill_tree_params(vr::KParams& k, const VrTreeOpaque* t) {
     k.nodes = t->nodes;
     k.leaves = t->leaves;
-    k.grid = t->grid;
-    k.grid_levels = t->grid_levels;
+    k.top = t->top;
+    k.bricks = t->bricks;
+    k.top_levels = t->top_levels;
+    k.brick_levels = t->brick_levels;
     k.extra = t->extra;
     for (int i = 0; i < 3; ++i) {
         k.offset[i] = t->desc.offset[i];
@@ -357,8 +394,19 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
         host_child = staged.data();
     }
     char why[256];
-    const int max_depth = validate_topology(host_child, d->capacity, N3, why, sizeof(why));
+    std::vector<uint8_t> level;
+    const int max_depth = validate_topology(host_child, d->capacity, N3, level, why, sizeof(why));
     if (max_depth < 0) return fail(VR_ERR_BAD_TREE, "bad tree: %s", why);
+    // Lookup structure (N == 2 fast path): leaves must sit within 24 levels (exact integer
+    // digits of a binary32 coordinate) and node*8+slot byte offsets must fit 32 bits.
+    int G0 = 0, BL = 0;
+    if (d->N == 2 && max_depth <= 23 && d->capacity < (1ll << 27)) {
+        const Tuning& tn = tuning();
+        G0 = tn.top_levels < 1 ? 1 : (tn.top_levels > 8 ? 8 : tn.top_levels);
+        if (G0 > max_depth + 1) G0 = max_depth + 1;  // deepest leaf depth
+        BL = tn.brick_levels < 1 ? 1 : (tn.brick_levels > 3 ? 3 : tn.brick_levels);
+        if (BL > max_depth + 1 - G0) BL = max_depth + 1 - G0;  // 0: the top grid resolves every leaf
+    }
 
     VrTreeOpaque* t = new (std::nothrow) VrTreeOpaque();
     if (!t) return fail(VR_ERR_OUT_OF_MEMORY, "host allocation failed");
@@ -411,8 +459,10 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
             t->n_cus = cus;
     }
     int32_t* d_perm = nullptr;
+    std::vector<int32_t> brick_roots;
     {
-        const std::vector<int32_t> perm = node_permutation(host_child, d->capacity, N3);
+        const std::vector<int32_t> perm =
+            node_permutation(host_child, d->capacity, N3, G0, BL, level, brick_roots);
         if (e == hipSuccess) e = hipMalloc((void**)&d_perm, perm.size() * sizeof(int32_t));
         if (e == hipSuccess)
             e = hipMemcpy(d_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice);
@@ -421,23 +471,39 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
         e = vr::launch_relayout(src_child, src_data, d_perm, t->nodes, t->leaves, (int64_t)n_slots,
                                 N3, d->data_dim, t->leaf_stride_h, nullptr);
     t->device_bytes = child_sz + leaves_sz + sizeof(uint32_t);
-    // restart grid: N == 2 only, node ids must fit the packed entry
-    t->grid_levels = 0;
-    if (e == hipSuccess && d->N == 2 && max_depth <= 23 && d->capacity < (1ll << 27)) {
-        int G = 8;
-        if (const char* env = getenv("VR_GRID_LEVELS")) G = atoi(env);
-        if (G > max_depth) G = max_depth;
-        if (G > 10) G = 10;  // 4 GB of grid at most (experiments; default 8 = 64 MB)
-        if (G >= 2) {
-            const size_t gsz = ((size_t)1 << (3 * G)) * sizeof(uint32_t);
-            e = hipMalloc((void**)&t->grid, gsz);
-            if (e == hipSuccess) e = vr::launch_build_grid(t->nodes, t->grid, G, nullptr);
-            if (e == hipSuccess) {
-                t->grid_levels = G;
-                t->device_bytes += gsz;
-            }
+    // lookup structure: top grid + bricks (vr_kernels.hip), built from the node words
+    int32_t* d_roots = nullptr;
+    if (e == hipSuccess && G0 > 0) {
+        const size_t top_sz = ((size_t)1 << (3 * G0)) * sizeof(uint2);
+        const int n_bricks = BL > 0 ? (int)brick_roots.size() : 0;
+        const size_t brick_sz = ((size_t)n_bricks << (3 * BL)) * sizeof(uint32_t);
+        e = hipMalloc((void**)&t->top, top_sz);
+        if (e == hipSuccess && n_bricks) e = hipMalloc((void**)&t->bricks, brick_sz);
+        if (e == hipSuccess && n_bricks) e = hipMalloc((void**)&d_roots, n_bricks * sizeof(int32_t));
+        if (e == hipSuccess && n_bricks)
+            e = hipMemcpy(d_roots, brick_roots.data(), n_bricks * sizeof(int32_t),
+                          hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = vr::launch_build_lookup(t->nodes, d_roots, n_bricks, t->top, t->bricks, G0, BL,
+                                        t->status, nullptr);
+        uint32_t flag = 0;
+        if (e == hipSuccess) e = hipMemcpy(&flag, t->status, sizeof(flag), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && flag != 0) {
+            if (d_roots) (void)hipFree(d_roots);
+            if (d_perm) (void)hipFree(d_perm);
+            if (d_child) (void)hipFree(d_child);
+            if (d_data) (void)hipFree(d_data);
+            vr_tree_free(t);
+            return fail(VR_ERR_BAD_TREE, "lookup structure build failed (flag %u)", flag);
+        }
+        if (e == hipSuccess) {
+            t->top_levels = G0;
+            t->brick_levels = n_bricks ? BL : 0;
+            t->n_bricks = n_bricks;
+            t->device_bytes += top_sz + brick_sz;
         }
     }
+    if (d_roots) (void)hipFree(d_roots);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (d_perm) (void)hipFree(d_perm);
     if (d_child) (void)hipFree(d_child);
@@ -490,7 +556,8 @@ int vr_tree_free(vr_tree_t t) {
     if (!t) return VR_OK;
     if (t->nodes) (void)hipFree(t->nodes);
     if (t->leaves) (void)hipFree(t->leaves);
-    if (t->grid) (void)hipFree(t->grid);
+    if (t->top) (void)hipFree(t->top);
+    if (t->bricks) (void)hipFree(t->bricks);
     if (t->extra) (void)hipFree(t->extra);
     if (t->status) (void)hipFree(t->status);
     if (t->sched_stats) (void)hipFree(t->sched_stats);
@@ -579,6 +646,8 @@ int vr_set_tuning(const char* key, int value) {
     else if (!strcmp(key, "frame_minor")) tn.frame_minor = value != 0;
     else if (!strcmp(key, "xcd_queues")) tn.xcd_queues = value != 0;
     else if (!strcmp(key, "chunk_max")) tn.chunk_max = value < 64 ? 64 : (value & ~63);
+    else if (!strcmp(key, "top_levels")) tn.top_levels = value;
+    else if (!strcmp(key, "brick_levels")) tn.brick_levels = value;
     else return fail(VR_ERR_INVALID_ARGUMENT, "unknown tuning key '%s'", key);
     return VR_OK;
 }

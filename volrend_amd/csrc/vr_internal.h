@@ -35,7 +35,8 @@ struct KParams {
     // ---- tree (TreeSpec, data_spec.hpp:23-50), device layout ----
     const uint32_t* nodes;    // one word per child slot (vr_kernels.hip)
     const uint16_t* leaves;   // padded coefficient records
-    const uint32_t* grid;     // top-level restart grid (N == 2) or NULL
+    const uint2* top;         // N == 2: 8^top_levels cells, see "lookup structure" in vr_kernels.hip
+    const uint32_t* bricks;   // N == 2: n_bricks * 8^brick_levels entries
     const float* extra;
     float offset[3];
     float scale[3];
@@ -46,7 +47,8 @@ struct KParams {
     int32_t basis_dim;
     int32_t leaf_stride_h;    // fp16 elements between padded records
     int32_t max_depth;        // deepest leaf level (child words read - 1)
-    int32_t grid_levels;      // G: grid has 2^G cells per axis (0 = no grid)
+    int32_t top_levels;       // G0: the top grid has 2^G0 cells per axis (0 = no lookup structure)
+    int32_t brick_levels;     // BL: a brick has 2^BL entries per axis (0 = no bricks)
     float ndc_width, ndc_height, ndc_focal;
     // ---- camera intrinsics (CameraSpec, data_spec.hpp:11-22); poses are per frame ----
     int32_t width, height;
@@ -114,6 +116,9 @@ hipError_t launch_relayout(const int32_t* child, const uint16_t* data, const int
 hipError_t launch_decode_quant(const uint16_t* colors, const uint16_t* map, const uint16_t* sigma,
                                const uint16_t* retained, uint16_t* data, int64_t n_slots,
                                int n_quant, int n_ret, int data_dim, hipStream_t stream);
-hipError_t launch_build_grid(const uint32_t* nodes, uint32_t* grid, int G, hipStream_t stream);
+// N == 2 lookup structure (top grid + bricks), built from the re-laid-out node words
+hipError_t launch_build_lookup(const uint32_t* nodes, const int32_t* brick_root, int n_bricks,
+                               uint2* top, uint32_t* bricks, int top_levels, int brick_levels,
+                               uint32_t* error_flag, hipStream_t stream);
 
 }  // namespace vr

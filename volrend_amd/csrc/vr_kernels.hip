@@ -6,7 +6,7 @@
 // maybe_precalc_basis (include/volrend/internal/lumisphere.hpp:9-87) -- written
 // from the algorithm, not from the CUDA text: wave64 8x8 pixel tiles, a device
 // re-layout built at upload (sigma packed into the node words, padded 16-byte
-// aligned SH records, a top-level restart grid), integer digit descent for N=2
+// aligned SH records, a top grid + bricks lookup structure), integer digit descent for N=2
 // (bit-identical to the float descent, see query_n2), march/shade phase split,
 // deterministic expf, explicit FP contraction policy.
 //
@@ -136,13 +136,25 @@ __device__ __forceinline__ void precalc_basis(const KParams& p, const float* dir
 //   leaves[capacity*N3*stride] the data_dim-1 colour coefficients of each slot,
 //     fp16, zero padded to `stride` bytes (16-byte aligned; 128 B = one cache
 //     line for SH16) so a record is read with a few aligned 16-byte loads.
-//   grid[8^G]            (N == 2) for every cell of the 2^G-per-axis grid the
-//     deepest node at level <= G containing it: (level << 27) | node.  A sample
-//     whose previous parent node does not contain it restarts here instead of
-//     at the root -- same leaf, same bits, ~3x fewer dependent loads.
+//   Lookup structure (N == 2), built from nodes[] at upload.  A sample resolves its leaf with
+//   ONE load when it stays inside the top cell of the previous sample, and without a loop for
+//   trees of up to G0 + BL levels (lego-class trees: 9):
+//   top[8^G0]  uint2     one entry per cell of the 2^G0-per-axis grid (default G0 = 6: 2 MB)
+//        .x bit31 = 1 : the cell lies inside ONE leaf of depth d <= G0 (extent 2^-d):
+//                       .x = leaf | d << 16 | sigma(fp16),  .y = leaf id (slot index)
+//        .x bit31 = 0 : the cell is an internal node of level G0 with a brick:
+//                       .x = brick index,  .y = that node's index
+//   bricks[n_bricks * 8^BL]  u32   (default BL = 3: 512 entries = 2 KB per brick) entry per
+//        cell of the 2^BL-per-axis subdivision of a top cell:
+//        bit31 = 1 : inside one leaf of depth d = G0 + 1 + drel:
+//                    leaf | drel << 26 | delta << 19 | slot << 16 | sigma(fp16), where the leaf
+//                    is child `slot` of node root + delta (the brick root's descendants of the
+//                    next BL - 1 levels are numbered right behind it: delta <= 72)
+//        bit31 = 0 : an internal node of level G0 + BL: its index; the walk continues there
+//                    with one child-word load per level.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kLeafBit = 0x80000000u;
-constexpr int kGridNodeBits = 27;
+constexpr int kMaxBrickLevels = 3;   // delta field: 8 + 64 nodes below a brick root
 
 // octree point query, n3tree_query.hpp:13-48 -- literal float descent (any N).
 // xyz is rewritten to leaf-local coordinates; returns the leaf slot index.
@@ -179,20 +191,21 @@ __device__ __forceinline__ int64_t query_generic(const KParams& p, float* xyz, f
     return sub_ptr;
 }
 
-// Per-lane traversal cache for the N == 2 integer descent.
+// Per-lane traversal cache for the N == 2 lookup: the top cell of the previous sample and
+// its entry.
 struct Cursor {
-    uint32_t ux = 0, uy = 0, uz = 0;  // 24-bit cell coordinates of the previous sample
-    uint32_t node = 0;                // node that contained the previous leaf
-    int level = 0;                    // its level (0 = root, which contains everything)
+    uint32_t cell = 0xFFFFFFFFu;  // top cell index (no sample yet: matches nothing)
+    uint32_t e0 = 0, e1 = 0;      // top[cell]
 };
 
 // N == 2: the float recurrence {x*=2; k=floor(x); x-=k} is exact in binary32, so
 // the level-l digit is bit (23-l) of floor(x * 2^24) and the leaf-local
-// coordinate is fract(x * 2^(l+1)) -- same leaf, same bits, no float chain.
-// Valid while the deepest leaf has l <= 23 (checked at upload).
-template <bool USE_GRID>
-__device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, float* cube_sz,
-                                             int* levels, uint32_t* word, Cursor& cur) {
+// coordinate is fract(x * 2^d) for a leaf of depth d -- same leaf, same bits, no float
+// chain, and the digits of several levels index a table at once.
+// Valid while the deepest leaf has d <= 24 (checked at upload).
+// Returns the leaf id; *depth = d (child words the reference reads = d), *word low 16 bits = sigma.
+__device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* depth,
+                                             uint32_t* word, Cursor& cur) {
     const float hi = 1.f - 1e-6f;
     xyz[0] = vmax(vmin(xyz[0], hi), 0.f);
     xyz[1] = vmax(vmin(xyz[1], hi), 0.f);
@@ -200,49 +213,52 @@ __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, float
     const uint32_t ux = (uint32_t)(xyz[0] * 16777216.f);
     const uint32_t uy = (uint32_t)(xyz[1] * 16777216.f);
     const uint32_t uz = (uint32_t)(xyz[2] * 16777216.f);
-    uint32_t node;
-    int l;
-    // does the node that held the previous leaf still contain this point?
-    const uint32_t diff = (ux ^ cur.ux) | (uy ^ cur.uy) | (uz ^ cur.uz);
-    if ((diff >> (24 - cur.level)) == 0u || cur.level == 0) {
-        node = cur.node;
-        l = cur.level;
-    } else if (USE_GRID && p.grid_levels > 0) {
-        const int g = p.grid_levels, sh = 24 - g;
-        const uint32_t cell = ((ux >> sh) << (2 * g)) | ((uy >> sh) << g) | (uz >> sh);
-        const uint32_t e = p.grid[cell];
-        node = e & ((1u << kGridNodeBits) - 1u);
-        l = (int)(e >> kGridNodeBits);
+    const uint32_t g0 = (uint32_t)p.top_levels, sh0 = 24u - g0;
+    const uint32_t cell = ((ux >> sh0) << (2u * g0)) | ((uy >> sh0) << g0) | (uz >> sh0);
+    if (cell != cur.cell) {
+        const uint2 e = p.top[cell];
+        cur.cell = cell;
+        cur.e0 = e.x;
+        cur.e1 = e.y;
+    }
+    uint32_t w = cur.e0, id = cur.e1;
+    int d;
+    if (w & kLeafBit) {
+        d = (int)__builtin_amdgcn_ubfe(w, 16u, 5u);
     } else {
-        node = 0;
-        l = 0;
+        const uint32_t bl = (uint32_t)p.brick_levels, sh1 = sh0 - bl;
+        const uint32_t sub = (__builtin_amdgcn_ubfe(ux, sh1, bl) << (2u * bl)) |
+                             (__builtin_amdgcn_ubfe(uy, sh1, bl) << bl) |
+                             __builtin_amdgcn_ubfe(uz, sh1, bl);
+        w = p.bricks[(w << (3u * bl)) + sub];
+        if (w & kLeafBit) {
+            d = (int)(g0 + 1u + __builtin_amdgcn_ubfe(w, 26u, 2u));
+            id = (id << 3) + __builtin_amdgcn_ubfe(w, 16u, 10u);  // (root + delta) * 8 + slot
+        } else {
+            // deeper than the brick: one child word per level (32-bit byte offsets: the node
+            // array is < 4 GB, checked at upload)
+            const char* nodes_base = reinterpret_cast<const char*>(p.nodes);
+            uint32_t node = w, slot;
+            int l = (int)(g0 + bl);
+            for (;; ++l) {
+                const uint32_t sh = (uint32_t)(23 - l);
+                slot = (__builtin_amdgcn_ubfe(ux, sh, 1u) << 2) |
+                       (__builtin_amdgcn_ubfe(uy, sh, 1u) << 1) | __builtin_amdgcn_ubfe(uz, sh, 1u);
+                w = *reinterpret_cast<const uint32_t*>(nodes_base + (node * 8u + slot) * 4u);
+                if ((w & kLeafBit) || l >= 23) break;
+                node = w;
+            }
+            d = l + 1;
+            id = node * 8u + slot;
+        }
     }
-    // One dependent 4-byte gather per level: slot = the three level-l digits; the node
-    // array is < 4 GB, so a 32-bit byte offset off the (scalar) base is enough.
-    const char* nodes_base = reinterpret_cast<const char*>(p.nodes);
-    uint32_t slot, w;
-    for (;; ++l) {
-        const uint32_t sh = (uint32_t)(23 - l);
-        slot = (__builtin_amdgcn_ubfe(ux, sh, 1u) << 2) | (__builtin_amdgcn_ubfe(uy, sh, 1u) << 1) |
-               __builtin_amdgcn_ubfe(uz, sh, 1u);
-        const uint32_t byte_off = (node * 8u + slot) * 4u;
-        w = *reinterpret_cast<const uint32_t*>(nodes_base + byte_off);
-        if ((w & kLeafBit) || l >= 23) break;
-        node = w;
-    }
-    cur.ux = ux;
-    cur.uy = uy;
-    cur.uz = uz;
-    cur.node = node;
-    cur.level = l;
-    const float cs = u2f((uint32_t)(127 + l + 1) << 23);  // 2^(l+1)
-    *cube_sz = u2f((uint32_t)(127 - l - 1) << 23);         // 2^-(l+1): x / 2^k == x * 2^-k exactly
-    *levels = l + 1;
+    *depth = d;
     *word = w;
+    const float cs = u2f((uint32_t)(127 + d) << 23);  // 2^d
     xyz[0] = __builtin_amdgcn_fractf(xyz[0] * cs);
     xyz[1] = __builtin_amdgcn_fractf(xyz[1] * cs);
     xyz[2] = __builtin_amdgcn_fractf(xyz[2] * cs);
-    return node * 8u + slot;
+    return id;
 }
 
 // rt_core.cuh:37-49
@@ -1002,11 +1018,11 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 pos[0] = P::madd(ray.t, ray.dir[0], ray.cen[0]);
                 pos[1] = P::madd(ray.t, ray.dir[1], ray.cen[1]);
                 pos[2] = P::madd(ray.t, ray.dir[2], ray.cen[2]);
-                float cube_sz;
+                float cube_sz = 0.f;
                 int levels;
                 uint32_t word;
                 if (N2) {
-                    leaf = query_n2<true>(p, pos, &cube_sz, &levels, &word, cur);
+                    leaf = query_n2(p, pos, &levels, &word, cur);
                 } else {
                     leaf = (uint32_t)query_generic<FMA>(p, pos, &cube_sz, &levels, &word);
                 }
@@ -1014,11 +1030,11 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     rc.samples++;
                     rc.child_reads += (uint32_t)levels;
                 }
-                // rt_core.cuh:116: dda / cube_sz.  For N == 2 cube_sz is a power of two and
-                // query_n2 hands back its reciprocal: the product is the same real number
-                // rounded once, i.e. bit-identical to the IEEE division.
+                // rt_core.cuh:116: dda / cube_sz
                 const float dda = dda_unit<FMA>(pos, ray.invdir);
-                const float t_subcube = N2 ? dda * cube_sz : dda / cube_sz;
+                // N2: cube_sz = 2^levels; x / 2^k == ldexp(x, -k), the same real number rounded once
+                const float t_subcube =
+                    N2 ? __builtin_amdgcn_ldexpf(dda, -levels) : dda / cube_sz;
                 const float delta_t = t_subcube + p.step_size;
                 const float sigma = h2f((uint16_t)(word & 0xFFFFu));
                 bool stop = false;
@@ -1374,23 +1390,69 @@ __global__ void decode_quant_kernel(const uint16_t* __restrict__ colors,
     }
 }
 
-// grid[cell] = deepest node at level <= G that contains the cell
-__global__ void build_grid_kernel(const uint32_t* nodes, uint32_t* grid, int G) {
+// Lookup structure, part 1: top[cell] for every cell of the 2^G0-per-axis grid (layout comment
+// at the top of this file).  brick_root[] = indices of the internal nodes of level G0, ascending.
+__global__ void build_top_kernel(const uint32_t* nodes, const int32_t* brick_root, int n_bricks,
+                                 uint2* top, int G0, uint32_t* error_flag) {
     const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n_cells = 1u << (3 * G);
-    if (cell >= n_cells) return;
-    const uint32_t mask = (1u << G) - 1u;
-    const uint32_t cx = (cell >> (2 * G)) & mask, cy = (cell >> G) & mask, cz = cell & mask;
+    if (cell >= (1u << (3 * G0))) return;
+    const uint32_t mask = (1u << G0) - 1u;
+    const uint32_t cx = (cell >> (2 * G0)) & mask, cy = (cell >> G0) & mask, cz = cell & mask;
     uint32_t node = 0;
-    int l = 0;
-    for (; l < G; ++l) {
-        const int sh = G - 1 - l;
+    for (int l = 0; l < G0; ++l) {
+        const int sh = G0 - 1 - l;
         const uint32_t slot = (((cx >> sh) & 1u) << 2) | (((cy >> sh) & 1u) << 1) | ((cz >> sh) & 1u);
         const uint32_t w = nodes[(uint64_t)node * 8u + slot];
-        if (w & kLeafBit) break;
+        if (w & kLeafBit) {
+            top[cell] = make_uint2(kLeafBit | ((uint32_t)(l + 1) << 16) | (w & 0xFFFFu),
+                                   node * 8u + slot);
+            return;
+        }
         node = w;
     }
-    grid[cell] = ((uint32_t)l << kGridNodeBits) | node;
+    // internal node of level G0: find its brick
+    int lo = 0, hi = n_bricks - 1, found = -1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint32_t r = (uint32_t)brick_root[mid];
+        if (r == node) {
+            found = mid;
+            break;
+        }
+        if (r < node) lo = mid + 1; else hi = mid - 1;
+    }
+    if (found < 0) {
+        atomicOr(error_flag, 1u);  // host and device disagree on the level-G0 nodes
+        found = 0;
+    }
+    top[cell] = make_uint2((uint32_t)found, node);
+}
+
+// Lookup structure, part 2: one thread per brick entry.
+__global__ void build_bricks_kernel(const uint32_t* nodes, const int32_t* brick_root, int n_bricks,
+                                    uint32_t* bricks, int BL, uint32_t* error_flag) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t per = 1u << (3 * BL);
+    if (gid >= (uint64_t)n_bricks * per) return;
+    const uint32_t b = (uint32_t)(gid >> (3 * BL)), e = (uint32_t)gid & (per - 1u);
+    const uint32_t mask = (1u << BL) - 1u;
+    const uint32_t ex = (e >> (2 * BL)) & mask, ey = (e >> BL) & mask, ez = e & mask;
+    const uint32_t root = (uint32_t)brick_root[b];
+    uint32_t node = root;
+    for (int k = 0; k < BL; ++k) {
+        const int sh = BL - 1 - k;
+        const uint32_t slot = (((ex >> sh) & 1u) << 2) | (((ey >> sh) & 1u) << 1) | ((ez >> sh) & 1u);
+        const uint32_t w = nodes[(uint64_t)node * 8u + slot];
+        if (w & kLeafBit) {
+            const uint32_t delta = node - root;
+            if (delta > 127u) atomicOr(error_flag, 2u);  // numbering contract broken
+            bricks[gid] = kLeafBit | ((uint32_t)k << 26) | ((delta & 127u) << 19) | (slot << 16) |
+                          (w & 0xFFFFu);
+            return;
+        }
+        node = w;
+    }
+    bricks[gid] = node;  // internal node of level G0 + BL
 }
 
 template <int FMA, int MODE>
@@ -1422,8 +1484,7 @@ hipError_t launch_basis(const KParams& p, dim3 grid, dim3 block, hipStream_t s) 
 
 template <int FMA>
 hipError_t launch_fp(const KParams& p, dim3 grid, dim3 block, hipStream_t s) {
-    // query_n2 forms node*8+slot and its byte offset in 32 bits: capacity < 2^27
-    const bool n2 = (p.N == 2) && p.max_depth <= 23 && p.capacity < (1ll << 27);
+    const bool n2 = (p.N == 2) && p.top_levels > 0;  // built at upload when the tree qualifies
     const bool lobes = p.format == VR_FORMAT_SG || p.format == VR_FORMAT_ASG;
     if (!n2) return launch_basis<FMA, MODE_GENERIC>(p, grid, block, s);
     if (lobes || p.instrumented) return launch_basis<FMA, MODE_FULL>(p, grid, block, s);
@@ -1512,10 +1573,17 @@ hipError_t launch_relayout(const int32_t* child, const uint16_t* data, const int
     return hipGetLastError();
 }
 
-hipError_t launch_build_grid(const uint32_t* nodes, uint32_t* grid, int G, hipStream_t stream) {
-    const uint32_t n_cells = 1u << (3 * G);
-    hipLaunchKernelGGL(build_grid_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, stream, nodes,
-                       grid, G);
+hipError_t launch_build_lookup(const uint32_t* nodes, const int32_t* brick_root, int n_bricks,
+                               uint2* top, uint32_t* bricks, int top_levels, int brick_levels,
+                               uint32_t* error_flag, hipStream_t stream) {
+    const uint32_t n_cells = 1u << (3 * top_levels);
+    hipLaunchKernelGGL(build_top_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, stream, nodes,
+                       brick_root, n_bricks, top, top_levels, error_flag);
+    if (n_bricks > 0 && brick_levels > 0) {
+        const uint64_t n = (uint64_t)n_bricks << (3 * brick_levels);
+        hipLaunchKernelGGL(build_bricks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           stream, nodes, brick_root, n_bricks, bricks, brick_levels, error_flag);
+    }
     return hipGetLastError();
 }
 
