@@ -335,7 +335,7 @@ def test_lookup_structure_geometries(torch_cuda, top_levels, brick_levels, fp_mo
         cnt_g = dict(zip(_abi.COUNTER_FIELDS, [int(v) for v in counters.cpu().tolist()]))
         t.free_device()
     finally:
-        api.set_tuning(top_levels=6, brick_levels=3)
+        api.set_tuning(top_levels=0, brick_levels=3)
     assert_parity(rgba_g, acc_g, rgba_o, acc_o)
     assert cnt_g == cnt
     assert np.array_equal(img.cpu().numpy(), rgba_o)

@@ -33,12 +33,12 @@ int fail(int code, const char* fmt, ...) {
 struct Tuning {
     int march_max = 16;
     int refill_min = 24;
-    int waves_per_cu = 20;
+    int waves_per_cu = 0;   // 0: what the kernel flavour fits (vr_kernels.hip waves_per_cu<>)
     int shade_min = 48;
     int frame_minor = 1;
     int xcd_queues = 1;
     int chunk_max = 4096;
-    int top_levels = 6;    // lookup structure of trees uploaded from now on (vr_kernels.hip)
+    int top_levels = 0;    // lookup structure of trees uploaded from now on (vr_kernels.hip); 0 = auto
     int brick_levels = 3;
 };
 Tuning& tuning() {
@@ -46,7 +46,7 @@ Tuning& tuning() {
         Tuning x;
         if (const char* e = getenv("VR_MARCH_MAX")) x.march_max = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_REFILL_MIN")) x.refill_min = atoi(e) < 1 ? 1 : atoi(e);
-        if (const char* e = getenv("VR_WAVES_PER_CU")) x.waves_per_cu = atoi(e) < 1 ? 1 : atoi(e);
+        if (const char* e = getenv("VR_WAVES_PER_CU")) x.waves_per_cu = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("VR_SHADE_MIN")) x.shade_min = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_FRAME_MINOR")) x.frame_minor = atoi(e) != 0;
         if (const char* e = getenv("VR_XCD_QUEUES")) x.xcd_queues = atoi(e) != 0;
@@ -402,7 +402,12 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     int G0 = 0, BL = 0;
     if (d->N == 2 && max_depth <= 23 && d->capacity < (1ll << 27)) {
         const Tuning& tn = tuning();
-        G0 = tn.top_levels < 1 ? 1 : (tn.top_levels > 8 ? 8 : tn.top_levels);
+        // auto: top grid + brick reach the deepest leaf (depth max_depth + 1) without a child-word
+        // walk where a top grid of <= 256^3 cells allows it -- 64^3 (2 MB) for lego-class trees of
+        // 9 levels, 128^3 for 10 (measured: C1 0.269 ms at (6,3) against 0.301 at (5,3); C3 0.790
+        // at (7,3) against 0.847 at (6,3))
+        G0 = tn.top_levels > 0 ? tn.top_levels : (max_depth + 1 - 3 < 6 ? 6 : max_depth + 1 - 3);
+        if (G0 > 8) G0 = 8;
         if (G0 > max_depth + 1) G0 = max_depth + 1;  // deepest leaf depth
         BL = tn.brick_levels < 1 ? 1 : (tn.brick_levels > 3 ? 3 : tn.brick_levels);
         if (BL > max_depth + 1 - G0) BL = max_depth + 1 - G0;  // 0: the top grid resolves every leaf
@@ -641,7 +646,7 @@ int vr_set_tuning(const char* key, int value) {
     Tuning& tn = tuning();
     if (!strcmp(key, "march_max")) tn.march_max = value < 1 ? 1 : value;
     else if (!strcmp(key, "refill_min")) tn.refill_min = value < 1 ? 1 : (value > 64 ? 64 : value);
-    else if (!strcmp(key, "waves_per_cu")) tn.waves_per_cu = value < 1 ? 1 : (value > 32 ? 32 : value);
+    else if (!strcmp(key, "waves_per_cu")) tn.waves_per_cu = value < 0 ? 0 : (value > 32 ? 32 : value);
     else if (!strcmp(key, "shade_min")) tn.shade_min = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "frame_minor")) tn.frame_minor = value != 0;
     else if (!strcmp(key, "xcd_queues")) tn.xcd_queues = value != 0;
@@ -749,8 +754,8 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.wblocks_per_tile = (k.tile_w / 8) * (k.tile_h / 8);
     k.n_wave_blocks = (int64_t)k.n_local_tiles * k.wblocks_per_tile;
     const int64_t total = k.n_wave_blocks * 64 * n_frames;
-    if (total >= (1ll << 32))
-        return fail(VR_ERR_INVALID_ARGUMENT, "batch of %lld rays exceeds the 32-bit ray queue",
+    if (total >= (1ll << 30))  // ray-buffer fields are addressed with 32-bit byte offsets
+        return fail(VR_ERR_INVALID_ARGUMENT, "batch of %lld rays exceeds the 2^30-ray queue",
                     (long long)total);
     k.total_rays = (uint32_t)total;
     k.n_frames = n_frames;
@@ -813,7 +818,7 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
         }
         HIP_TRY(vr::launch_prepare(k, tbl, hs));
     }
-    HIP_TRY(vr::launch_render(k, f->fp_mode, t->n_cus * tn.waves_per_cu, hs));
+    HIP_TRY(vr::launch_render(k, f->fp_mode, t->n_cus, tn.waves_per_cu, hs));
     HIP_TRY(hipEventRecord(ls.done, hs));
     ls.used = true;
     return VR_OK;
@@ -827,8 +832,8 @@ int vr_reserve(vr_tree_t t, int width, int height, int n_frames) {
                     height, n_frames);
     // whole frames (world = 1), rounded up to 8x8 wave blocks like tile_geometry does
     const int64_t total = (int64_t)((width + 7) / 8) * ((height + 7) / 8) * 64 * n_frames;
-    if (total >= (1ll << 32))
-        return fail(VR_ERR_INVALID_ARGUMENT, "batch of %lld rays exceeds the 32-bit ray queue",
+    if (total >= (1ll << 30))
+        return fail(VR_ERR_INVALID_ARGUMENT, "batch of %lld rays exceeds the 2^30-ray queue",
                     (long long)total);
     const size_t need = ray_buffer_bytes((uint32_t)total, basis_words_of(t));
     std::lock_guard<std::mutex> guard(t->launch_mutex);

@@ -100,7 +100,8 @@ struct KParams {
 
 // vr_kernels.hip
 hipError_t launch_prepare(const KParams& p, const FrameTable& tbl, hipStream_t stream);
-hipError_t launch_render(const KParams& p, int fp_mode, int n_waves, hipStream_t stream);
+hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_override,
+                         hipStream_t stream);
 hipError_t launch_assemble(uint8_t* frame, int64_t pitch, const uint8_t* gathered, int width,
                            int height, int tile_w, int tile_h, int world, int n_frames,
                            int64_t out_stride, int64_t rank_stride, int64_t in_stride,

@@ -27,7 +27,10 @@ constexpr int kWave = 64;
                        // sched_stats (profiling builds only; costs a few s_memtime per iteration)
 #endif
 #ifndef VR_MIN_WAVES_PER_EU
-#define VR_MIN_WAVES_PER_EU 5
+#define VR_MIN_WAVES_PER_EU 8  // cap on the per-flavour register bounds (experiments)
+#endif
+#ifndef VR_SH16_ROWS
+#define VR_SH16_ROWS 56  // SH16 items per shade round (64: one more LDS granule, 20 waves per CU)
 #endif
 constexpr int kMaxIter = 1 << 22;  // guard against step_size <= 0 (upstream would spin forever)
 
@@ -660,9 +663,12 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
 // Wave-private LDS of the march kernel (one wave per workgroup):
 //   ring  : colour work items (leaf, weight, owner lane) in sample order
 //   stage : the SH records of one shade round, DMA'd straight from HBM (global_load_lds)
-//   res   : the three colour contributions of each item of the round
-// The basis of a lane's ray lives in that lane's registers; the lane that shades one of its
-// items reads it through the LDS crossbar (ds_bpermute).
+//   res   : the three colour contributions of each item of the round (aliases the first
+//           768 bytes of `stage`: every row has been consumed by then)
+// The basis of a ray stays in the ray buffer: the lane that shades one of its items fetches the
+// owner's ray id through the LDS crossbar (one ds_bpermute) and reads the basis words from
+// there (coalesced: the rays of a wave have near-consecutive ids; issued ahead of the record
+// DMA, so both latencies overlap) -- 16 VGPRs of per-ray state less than carrying it.
 // ---------------------------------------------------------------------------
 constexpr int kRayWords = 15;
 constexpr int kRing = 128;   // capacity; at most 127 items are ever outstanding
@@ -679,9 +685,16 @@ struct Stage {
     static constexpr int kVec = kEnabled ? RecTraits<BASIS>::kDwords / 4 : 1;  // V: 2, 4, 6, 10
     static constexpr int kRow = kVec * 16;                            // bytes
     static constexpr int kPerInstr = kWave / kVec;                    // records per DMA instruction
-    static constexpr int kPass = kRow * kWave <= 6144 ? kWave : kWave / 2;  // records per pass
+    // LDS budget: ring (1152 B) + stage <= 6656 B = 24 waves per CU.  SH16 (96-byte rows) shades
+    // VR_SH16_ROWS = 56 items per round in one pass, SH25 (160-byte rows) 64 items in two passes
+    // of 32, the narrower formats 64 items in one pass.
+    static constexpr int kPass = !kEnabled ? kWave
+                                 : (kRow * kWave <= 5504 ? kWave
+                                    : (BASIS == BASIS_16 ? VR_SH16_ROWS : kWave / 2));  // rows per pass
+    static constexpr int kPasses = (BASIS == BASIS_25) ? 2 : 1;
+    static constexpr int kShade = kPass * kPasses;                    // items per shade round
     static constexpr int kInstr = (kPass + kPerInstr - 1) / kPerInstr;
-    static constexpr int kBytes = kEnabled ? kPass * kRow : 16;
+    static constexpr int kBytes = (kEnabled && kPass * kRow > 768) ? kPass * kRow : 768;
 };
 typedef __attribute__((address_space(1))) const void* vr_gptr_t;
 typedef __attribute__((address_space(3))) void* vr_lptr_t;
@@ -691,12 +704,22 @@ typedef __attribute__((address_space(3))) void* vr_lptr_t;
 constexpr int kOwnerQ = VR_OWNER_Q;  // outstanding items per ray (8-bit ring positions, packed)
 typedef std::conditional<(VR_OWNER_Q > 4), uint64_t, uint32_t>::type qpos_t;
 
-// Register budget: 5 waves/SIMD (<= 96 VGPRs) for the production flavours; the SH25 and the
-// instrumented / generic flavours keep their wider state in registers at 4 waves/SIMD.
+// Register budget of the production (FAST) flavours, from their natural register use: SH16 <= 80
+// VGPRs (6 waves per SIMD -- with its 6.4 KB of LDS that is 24 waves per CU), SH9 <= 72 (7),
+// SH25 <= 96 (5), the small records 8.  The instrumented / lobe / generic flavours keep their
+// wider state in registers at 4 waves per SIMD.
 template <int BASIS, int MODE>
 constexpr int min_waves_per_eu() {
-    return (BASIS == BASIS_25 || MODE != MODE_FAST) && VR_MIN_WAVES_PER_EU > 4 ? 4
-                                                                                : VR_MIN_WAVES_PER_EU;
+    if (MODE != MODE_FAST) return 4;
+    const int want = BASIS == BASIS_25 ? 5 : BASIS == BASIS_16 ? 6 : BASIS == BASIS_9 ? 7 : 8;
+    return want < VR_MIN_WAVES_PER_EU ? want : VR_MIN_WAVES_PER_EU;
+}
+// Waves one CU holds of a flavour: the register bound above or the LDS bound (512-byte granules).
+template <int BASIS, int MODE>
+constexpr int waves_per_cu() {
+    const int lds = ((kRing * 9 + Stage<BASIS>::kBytes + 511) / 512) * 512;
+    const int by_lds = 163840 / lds, by_reg = 4 * min_waves_per_eu<BASIS, MODE>();
+    return by_lds < by_reg ? by_lds : by_reg;
 }
 
 template <int FMA, int BASIS, int MODE>
@@ -713,10 +736,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     __shared__ float it_w[kRing];
     __shared__ uint8_t it_own[kRing];
     __shared__ __attribute__((aligned(16))) char stage[ST::kBytes];
-    __shared__ float res[3 * kWave];
-    float mybasis[NB];  // basis_fn of this lane's ray (rt_core.cuh:96-103), read by shader lanes
-#pragma unroll
-    for (int i = 0; i < NB; ++i) mybasis[i] = 0.f;
+    float* const res = reinterpret_cast<float*>(stage);  // 3 x 64 floats, see above
 
     const int lane = threadIdx.x & (kWave - 1);
     Ray ray;
@@ -725,6 +745,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     ray.frame = 0;
     ray.xy = 0;
     ray.pix_off = 0;
+    uint32_t ray_id = 0;  // index of the lane's ray in the ray buffer
     ray.iter = 0;
     ray.t = 0.f;
     ray.tmax = -1.f;
@@ -783,19 +804,24 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         const bool have = lane < n;
         const uint32_t jmine = (ring_head + (uint32_t)lane) & (kRing - 1);
         const float weight = have ? it_w[jmine] : 0.f;
-        // the basis of the ray that owns my item, out of its lane's registers (every lane
-        // executes the permutes: a bpermute only reads active lanes)
+        // the basis of the ray that owns my item (rt_core.cuh:96-103, evaluated by raygen_kernel):
+        // the owner's ray id through the LDS crossbar (every lane executes the permute: a
+        // bpermute only reads active lanes), the words out of the ray buffer
         float b[NB];
         if (HAS_BASIS) {
             const int own4 = have ? (int)it_own[jmine] << 2 : lane << 2;
+            const uint32_t rid4 = (uint32_t)__builtin_amdgcn_ds_bpermute(own4, (int)ray_id) << 2;
+            const char* fld = reinterpret_cast<const char*>(p.ray_buf + (size_t)kRayWords * cap);
 #pragma unroll
-            for (int i = 0; i < NB; ++i)
-                b[i] = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(own4, (int)f2u(mybasis[i])));
+            for (int i = 0; i < NB; ++i) {
+                b[i] = *reinterpret_cast<const float*>(fld + rid4);  // uniform base + 32-bit offset
+                fld += (size_t)cap * 4u;
+            }
         }
         float r0 = 0.f, r1 = 0.f, r2 = 0.f;
         if constexpr (ST::kEnabled) {
 #pragma unroll
-            for (int pass = 0; pass < kWave / ST::kPass; ++pass) {
+            for (int pass = 0; pass < ST::kPasses; ++pass) {
                 if (pass * ST::kPass < n) {  // wave-uniform
 #pragma unroll
                     for (int k = 0; k < ST::kInstr; ++k) {
@@ -844,7 +870,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                         }
 #endif
                     }
-                    if (ST::kPass < kWave) __syncthreads();  // rows are free for the next pass
+                    if (ST::kPasses > 1) __syncthreads();  // rows are free for the next pass
                     TL_ADD(tl_shade_math);
                 }
             }
@@ -861,6 +887,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 r2 = rec.at(2);
             }
         }
+        __syncthreads();  // every row has been read: `res` may overwrite them
         if (have) {
             res[0 * kWave + lane] = r0;
             res[1 * kWave + lane] = r1;
@@ -907,6 +934,10 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 st_fin_l += (uint32_t)__builtin_popcountll(m_done);
             }
             if (done) {
+                const uint32_t* rb = p.ray_buf + ray_id;  // the pixel this ray belongs to
+                ray.xy = rb[(size_t)12 * cap];
+                ray.pix_off = rb[(size_t)13 * cap];
+                ray.frame = (int)rb[(size_t)14 * cap];
                 finish_ray<FMA, COUNT>(p, ray, rc);
                 ray.active = false;
             }
@@ -975,14 +1006,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                         ray.t = u2f(rb[(size_t)9 * cap]);
                         ray.tmax = u2f(rb[(size_t)10 * cap]);
                         ray.delta_scale = u2f(rb[(size_t)11 * cap]);
-                        ray.xy = rb[(size_t)12 * cap];
-                        ray.pix_off = rb[(size_t)13 * cap];
-                        ray.frame = (int)rb[(size_t)14 * cap];
-                        if (HAS_BASIS) {
-#pragma unroll
-                            for (int i = 0; i < NB; ++i)
-                                mybasis[i] = u2f(rb[(size_t)(kRayWords + i) * cap]);
-                        }
+                        ray_id = r;
                         ray.out[0] = ray.out[1] = ray.out[2] = ray.out[3] = 0.f;
                         ray.light = 1.f;
                         ray.active = ray.alive = ray.entered = true;
@@ -1081,12 +1105,15 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     ++qn;
                 }
                 ring_tail += (uint32_t)__builtin_popcountll(m_push);
-                if (ring_tail - ring_head >= (uint32_t)kWave) shade_chunk(kWave);
+                if (ring_tail - ring_head >= (uint32_t)ST::kShade) shade_chunk(ST::kShade);
             }
         }
         // nobody can march any more (queues full / rays ended): flush what is queued
-        if (ring_tail != ring_head && !wave_any(ray.active && ray.alive && qn < kOwnerQ))
-            shade_chunk((int)(ring_tail - ring_head));
+        // (at most kShade - 1 + 64 items wait here: two rounds at most)
+        while (ring_tail != ring_head && !wave_any(ray.active && ray.alive && qn < kOwnerQ)) {
+            const uint32_t waiting = ring_tail - ring_head;
+            shade_chunk(waiting < (uint32_t)ST::kShade ? (int)waiting : ST::kShade);
+        }
         TL_ADD(tl_march);
     }
 #if VR_TIMELINE
@@ -1455,8 +1482,12 @@ __global__ void build_bricks_kernel(const uint32_t* nodes, const int32_t* brick_
     bricks[gid] = node;  // internal node of level G0 + BL
 }
 
+// grid = the persistent waves: as many as the chip holds of this flavour (or the tuning
+// override), but no more than about one wave per 128 rays of a small launch
 template <int FMA, int MODE>
-hipError_t launch_basis(const KParams& p, dim3 grid, dim3 block, hipStream_t s) {
+hipError_t launch_basis(const KParams& p, int64_t want, int n_cus, int waves_override,
+                        hipStream_t s) {
+    const dim3 block(kWave);
     int b;
     if (p.basis_dim < 0 || p.format == VR_FORMAT_RGBA) {
         b = BASIS_RGBA;
@@ -1469,7 +1500,13 @@ hipError_t launch_basis(const KParams& p, dim3 grid, dim3 block, hipStream_t s) 
             default: b = BASIS_1; break;
         }
     }
-#define VR_LAUNCH(B) hipLaunchKernelGGL((render_kernel<FMA, B, MODE>), grid, block, 0, s, p)
+#define VR_LAUNCH(B)                                                                         \
+    do {                                                                                     \
+        const int64_t cap_ = (int64_t)n_cus * (waves_override > 0 ? waves_override           \
+                                                                  : waves_per_cu<B, MODE>()); \
+        const dim3 grid((unsigned)(want < cap_ ? want : cap_));                              \
+        hipLaunchKernelGGL((render_kernel<FMA, B, MODE>), grid, block, 0, s, p);             \
+    } while (0)
     switch (b) {
         case BASIS_RGBA: VR_LAUNCH(BASIS_RGBA); break;
         case BASIS_25: VR_LAUNCH(BASIS_25); break;
@@ -1483,12 +1520,13 @@ hipError_t launch_basis(const KParams& p, dim3 grid, dim3 block, hipStream_t s) 
 }
 
 template <int FMA>
-hipError_t launch_fp(const KParams& p, dim3 grid, dim3 block, hipStream_t s) {
+hipError_t launch_fp(const KParams& p, int64_t want, int n_cus, int waves_override, hipStream_t s) {
     const bool n2 = (p.N == 2) && p.top_levels > 0;  // built at upload when the tree qualifies
     const bool lobes = p.format == VR_FORMAT_SG || p.format == VR_FORMAT_ASG;
-    if (!n2) return launch_basis<FMA, MODE_GENERIC>(p, grid, block, s);
-    if (lobes || p.instrumented) return launch_basis<FMA, MODE_FULL>(p, grid, block, s);
-    return launch_basis<FMA, MODE_FAST>(p, grid, block, s);
+    if (!n2) return launch_basis<FMA, MODE_GENERIC>(p, want, n_cus, waves_override, s);
+    if (lobes || p.instrumented)
+        return launch_basis<FMA, MODE_FULL>(p, want, n_cus, waves_override, s);
+    return launch_basis<FMA, MODE_FAST>(p, want, n_cus, waves_override, s);
 }
 
 }  // namespace
@@ -1499,7 +1537,8 @@ hipError_t launch_prepare(const KParams& p, const FrameTable& tbl, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_render(const KParams& p, int fp_mode, int n_waves, hipStream_t stream) {
+hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_override,
+                         hipStream_t stream) {
     if (p.n_wave_blocks <= 0 || p.n_frames <= 0) return hipSuccess;
     const int64_t total_blocks = p.n_wave_blocks * p.n_frames;
     {   // ray generation: kGenWaves wave blocks (8x8 pixels each) per workgroup
@@ -1515,15 +1554,12 @@ hipError_t launch_render(const KParams& p, int fp_mode, int n_waves, hipStream_t
         }
     }
     // persistent march grid: enough waves to fill the chip, but no more than one per
-    // ~256 pixels so that small launches still rebalance through the ray queue
+    // ~128 pixels so that small launches still rebalance through the ray queue
     int64_t want = total_blocks / 2;  // about one wave per 64 rays that enter the volume
     if (want < 256) want = 256;
-    if (want > n_waves) want = n_waves;
     if (want > total_blocks) want = total_blocks;
-    const dim3 block(kWave);
-    const dim3 grid((unsigned)want);
-    const hipError_t e = fp_mode == VR_FP_FMA ? launch_fp<1>(p, grid, block, stream)
-                                              : launch_fp<0>(p, grid, block, stream);
+    const hipError_t e = fp_mode == VR_FP_FMA ? launch_fp<1>(p, want, n_cus, waves_override, stream)
+                                              : launch_fp<0>(p, want, n_cus, waves_override, stream);
     if (e != hipSuccess || !p.enable_probe || p.probe_disp_size <= 0) return e;
     const int side = p.probe_disp_size + 5;
     const dim3 pgrid((unsigned)((side * side + 255) / 256), (unsigned)p.n_frames);
