@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvolrend_hip.so")
+# VOLREND_HIP_LIB: a profiling / experiment build of the SAME library (python -m volrend_amd.build
+# --variant NAME -D...), never something else -- there is no fallback either way.
+LIB_PATH = os.environ.get("VOLREND_HIP_LIB") or os.path.join(HERE, "libvolrend_hip.so")
 
 VR_OK = 0
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3

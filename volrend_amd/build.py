@@ -36,16 +36,25 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, extra_flags=(), variant: str = "") -> str:
+    """variant: experiment / profiling build next to the product library
+    (libvolrend_hip_<variant>.so, selected at run time with VOLREND_HIP_LIB)."""
+    out = LIB if not variant else os.path.join(HERE, f"libvolrend_hip_{variant}.so")
+    if not variant and not force and not needs_build():
         return LIB
     cmd = [HIPCC, *FLAGS, *extra_flags, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    variant = ""
+    if "--variant" in args:
+        i = args.index("--variant")
+        variant = args[i + 1]
+        del args[i:i + 2]
+    print(build(force="--force" in sys.argv, verbose=True, extra_flags=args, variant=variant))

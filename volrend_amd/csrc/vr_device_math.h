@@ -82,6 +82,24 @@ static __device__ __forceinline__ float fma_half(float b, uint32_t w, float c) {
     return d;
 }
 
+// b * (float)h + c with TWO roundings (product, then sum) as one two-instruction unit:
+// bit-identical to mul_half(b, w) + c.  Written as one asm block so that the product never
+// lives longer than one instruction -- left to itself the scheduler computes every product of
+// a dot product up front (they are independent) and pays ~30 VGPRs for it.
+template <int HI>
+static __device__ __forceinline__ float mul_add_half(float b, uint32_t w, float c) {
+    float d, t;
+    if (HI)
+        asm("v_fma_mix_f32 %1, %2, %3, %4 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n\t"
+            "v_add_f32 %0, %1, %5"
+            : "=v"(d), "=&v"(t) : "v"(b), "v"(w), "s"(0x80000000u), "v"(c));
+    else
+        asm("v_fma_mix_f32 %1, %2, %3, %4 op_sel_hi:[0,1,0]\n\t"
+            "v_add_f32 %0, %1, %5"
+            : "=v"(d), "=&v"(t) : "v"(b), "v"(w), "s"(0x80000000u), "v"(c));
+    return d;
+}
+
 // vr_expf: the deterministic expf of DESIGN.md.  The reference calls CUDA's
 // expf (rt_core.cuh:119,160), whose bits depend on NVIDIA's ex2.approx; this is
 // a pure IEEE-op algorithm so host oracle and device agree bit for bit:

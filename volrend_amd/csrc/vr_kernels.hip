@@ -367,7 +367,7 @@ __device__ __forceinline__ float coef_mul(float b, const SRC& r) {
 template <int FMA, int E, typename SRC>  // Policy<FMA>::madd(b, coefficient E, c)
 __device__ __forceinline__ float coef_madd(float b, const SRC& r, float c) {
     if (FMA) return fma_half<E & 1>(b, r.template word<E>(), c);
-    return mul_half<E & 1>(b, r.template word<E>()) + c;
+    return mul_add_half<E & 1>(b, r.template word<E>(), c);
 }
 // g = b[LO]*v[LO] (+) b[LO+1]*v[LO+1] (+) ... (+) b[HI]*v[HI], coefficients at offset O
 template <int FMA, int O, int LO, int HI>
@@ -398,6 +398,73 @@ __device__ __forceinline__ float channel_dot(const float* basis_fn, const SRC& r
     if constexpr (BASIS >= 9) tmp += DotGroup<FMA, O, 4, 8>::run(basis_fn, r);
     if constexpr (BASIS >= 4) tmp += DotGroup<FMA, O, 1, 3>::run(basis_fn, r);
     return tmp;
+}
+
+// The words of a staged record (LDS row) that hold coefficients LO..HI of channel C.
+template <int BASIS, int C, int LO, int HI>
+struct GroupWin {
+    static constexpr int kW0 = (C * BASIS + LO) / 2, kW1 = (C * BASIS + HI) / 2;
+    uint32_t w[kW1 - kW0 + 1];
+    __device__ __forceinline__ void load(const char* row) {
+        const uint32_t* r32 = reinterpret_cast<const uint32_t*>(row);
+#pragma unroll
+        for (int j = 0; j <= kW1 - kW0; ++j) w[j] = r32[kW0 + j];
+    }
+    template <int E>
+    __device__ __forceinline__ uint32_t word() const {
+        return w[(E >> 1) - kW0];
+    }
+};
+
+// rt_core.cuh:131-160 for the three channels of one staged record, group by group: the group
+// sums are independent subexpressions of `tmp`, so each group's basis values are fetched
+// (get(i) = basis_fn[i] of the ray that owns the item) right before the three channels use
+// them and are dead afterwards -- the same operations in the same association as
+// channel_dot, with ~12 fewer live registers than gathering the whole basis up front.
+template <int FMA, int BASIS, int LO, int HI, typename GET>
+__device__ __forceinline__ void add_group(const char* row, GET&& get, float* acc) {
+    float b[VR_MAX_BASIS];
+    // keep the scheduler from hoisting the next group's fetches over this group's arithmetic:
+    // that is the register saving
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = LO; i <= HI; ++i) b[i] = get(i);
+    {
+        GroupWin<BASIS, 0, LO, HI> w;
+        w.load(row);
+        acc[0] += DotGroup<FMA, 0 * BASIS, LO, HI>::run(b, w);
+    }
+    {
+        GroupWin<BASIS, 1, LO, HI> w;
+        w.load(row);
+        acc[1] += DotGroup<FMA, 1 * BASIS, LO, HI>::run(b, w);
+    }
+    {
+        GroupWin<BASIS, 2, LO, HI> w;
+        w.load(row);
+        acc[2] += DotGroup<FMA, 2 * BASIS, LO, HI>::run(b, w);
+    }
+}
+
+template <int FMA, int BASIS, typename GET>
+__device__ __forceinline__ void channel_sums(const char* row, GET&& get, float* acc) {
+    static_assert(BASIS > 1, "SH / SG / ASG sizes only");
+    {
+        const float b0 = get(0);
+        GroupWin<BASIS, 0, 0, 0> w0;
+        GroupWin<BASIS, 1, 0, 0> w1;
+        GroupWin<BASIS, 2, 0, 0> w2;
+        w0.load(row);
+        w1.load(row);
+        w2.load(row);
+        acc[0] = coef_mul<0 * BASIS>(b0, w0);
+        acc[1] = coef_mul<1 * BASIS>(b0, w1);
+        acc[2] = coef_mul<2 * BASIS>(b0, w2);
+    }
+    if constexpr (BASIS == 25) add_group<FMA, BASIS, 16, 24>(row, get, acc);
+    if constexpr (BASIS >= 16) add_group<FMA, BASIS, 9, 15>(row, get, acc);
+    if constexpr (BASIS >= 9) add_group<FMA, BASIS, 4, 8>(row, get, acc);
+    if constexpr (BASIS >= 4) add_group<FMA, BASIS, 1, 3>(row, get, acc);
 }
 
 __device__ __forceinline__ uint32_t quant8(float v) {
@@ -665,10 +732,10 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
 //   stage : the SH records of one shade round, DMA'd straight from HBM (global_load_lds)
 //   res   : the three colour contributions of each item of the round (aliases the first
 //           768 bytes of `stage`: every row has been consumed by then)
-// The basis of a ray stays in the ray buffer: the lane that shades one of its items fetches the
-// owner's ray id through the LDS crossbar (one ds_bpermute) and reads the basis words from
-// there (coalesced: the rays of a wave have near-consecutive ids; issued ahead of the record
-// DMA, so both latencies overlap) -- 16 VGPRs of per-ray state less than carrying it.
+// The basis of a lane's ray lives in that lane's registers; the lane that shades one of its
+// items reads it through the LDS crossbar (ds_bpermute).  (Reading it from the ray buffer
+// instead frees 16 VGPRs but costs 37 % frame time: 16 more lines per shade round that the
+// record stream keeps evicting from L2 -- measured, profiles/r02_experiments.md.)
 // ---------------------------------------------------------------------------
 constexpr int kRayWords = 15;
 constexpr int kRing = 128;   // capacity; at most 127 items are ever outstanding
@@ -706,12 +773,12 @@ typedef std::conditional<(VR_OWNER_Q > 4), uint64_t, uint32_t>::type qpos_t;
 
 // Register budget of the production (FAST) flavours, from their natural register use: SH16 <= 80
 // VGPRs (6 waves per SIMD -- with its 6.4 KB of LDS that is 24 waves per CU), SH9 <= 72 (7),
-// SH25 <= 96 (5), the small records 8.  The instrumented / lobe / generic flavours keep their
+// SH25 <= 128 (4: it gathers its 25 basis values up front), the small records 8.  The instrumented / lobe / generic flavours keep their
 // wider state in registers at 4 waves per SIMD.
 template <int BASIS, int MODE>
 constexpr int min_waves_per_eu() {
     if (MODE != MODE_FAST) return 4;
-    const int want = BASIS == BASIS_25 ? 5 : BASIS == BASIS_16 ? 6 : BASIS == BASIS_9 ? 7 : 8;
+    const int want = BASIS == BASIS_25 ? 4 : BASIS == BASIS_16 ? 6 : BASIS == BASIS_9 ? 7 : 8;
     return want < VR_MIN_WAVES_PER_EU ? want : VR_MIN_WAVES_PER_EU;
 }
 // Waves one CU holds of a flavour: the register bound above or the LDS bound (512-byte granules).
@@ -737,6 +804,9 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     __shared__ uint8_t it_own[kRing];
     __shared__ __attribute__((aligned(16))) char stage[ST::kBytes];
     float* const res = reinterpret_cast<float*>(stage);  // 3 x 64 floats, see above
+    float mybasis[NB];  // basis_fn of this lane's ray (rt_core.cuh:96-103), read by shader lanes
+#pragma unroll
+    for (int i = 0; i < NB; ++i) mybasis[i] = 0.f;
 
     const int lane = threadIdx.x & (kWave - 1);
     Ray ray;
@@ -804,20 +874,24 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         const bool have = lane < n;
         const uint32_t jmine = (ring_head + (uint32_t)lane) & (kRing - 1);
         const float weight = have ? it_w[jmine] : 0.f;
-        // the basis of the ray that owns my item (rt_core.cuh:96-103, evaluated by raygen_kernel):
-        // the owner's ray id through the LDS crossbar (every lane executes the permute: a
-        // bpermute only reads active lanes), the words out of the ray buffer
-        float b[NB];
-        if (HAS_BASIS) {
-            const int own4 = have ? (int)it_own[jmine] << 2 : lane << 2;
-            const uint32_t rid4 = (uint32_t)__builtin_amdgcn_ds_bpermute(own4, (int)ray_id) << 2;
-            const char* fld = reinterpret_cast<const char*>(p.ray_buf + (size_t)kRayWords * cap);
+        // basis_fn[i] of the ray that owns my item, out of its lane's registers through the LDS
+        // crossbar (every lane executes the permute: a bpermute only reads active lanes)
+        const int own4 = (HAS_BASIS && have) ? (int)it_own[jmine] << 2 : lane << 2;
+        auto basis_of = [&](int i) -> float {
+            return u2f((uint32_t)__builtin_amdgcn_ds_bpermute(own4, (int)f2u(mybasis[i])));
+        };
+        // One-pass flavours fetch each group of basis values right where the (whole) wave uses
+        // it; the two-pass flavour (SH25) computes with half the wave at a time, so it gathers
+        // everything up front while every owner lane is still active.
+        float bfull[ST::kPasses > 1 ? NB : 1];
+        if constexpr (ST::kPasses > 1) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                b[i] = *reinterpret_cast<const float*>(fld + rid4);  // uniform base + 32-bit offset
-                fld += (size_t)cap * 4u;
-            }
+            for (int i = 0; i < NB; ++i) bfull[i] = basis_of(i);
         }
+        auto basis_get = [&](int i) -> float {
+            if constexpr (ST::kPasses > 1) return bfull[i];
+            else return basis_of(i);
+        };
         float r0 = 0.f, r1 = 0.f, r2 = 0.f;
         if constexpr (ST::kEnabled) {
 #pragma unroll
@@ -845,30 +919,15 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     }
                     __syncthreads();  // the DMAs have landed (vmcnt(0)) and are visible
                     TL_ADD(tl_shade_load);
-                    if (have && lane / ST::kPass == pass) {
+                    // (one pass: ALL lanes run the arithmetic -- an owner lane without an item
+                    // of its own must stay active for the permutes; only `have` lanes keep results)
+                    if (ST::kPasses == 1 || lane / ST::kPass == pass) {
                         const char* row = stage + (lane % ST::kPass) * ST::kRow;
-#if VR_ABLATE == 3   // timing experiment only: loads kept, SH / sigmoid arithmetic removed
-                        const uint4 v = *reinterpret_cast<const uint4*>(row);
-                        r0 = weight * u2f((v.x & 0x007FFFFFu) | 0x3F000000u) * b[0];
-                        r1 = weight * u2f((v.y & 0x007FFFFFu) | 0x3F000000u) * b[1];
-                        r2 = weight * u2f((v.z & 0x007FFFFFu) | 0x3F000000u) * b[2];
-#else
-                        {
-                            ChanWin<BASIS, 0> cw;
-                            cw.load(row);
-                            r0 = weight / (1.f + vr_expf(-channel_dot<FMA, BASIS, 0>(b, cw)));
-                        }
-                        {
-                            ChanWin<BASIS, 1> cw;
-                            cw.load(row);
-                            r1 = weight / (1.f + vr_expf(-channel_dot<FMA, BASIS, 1>(b, cw)));
-                        }
-                        {
-                            ChanWin<BASIS, 2> cw;
-                            cw.load(row);
-                            r2 = weight / (1.f + vr_expf(-channel_dot<FMA, BASIS, 2>(b, cw)));
-                        }
-#endif
+                        float acc[3];
+                        channel_sums<FMA, BASIS>(row, basis_get, acc);
+                        r0 = weight / (1.f + vr_expf(-acc[0]));
+                        r1 = weight / (1.f + vr_expf(-acc[1]));
+                        r2 = weight / (1.f + vr_expf(-acc[2]));
                     }
                     if (ST::kPasses > 1) __syncthreads();  // rows are free for the next pass
                     TL_ADD(tl_shade_math);
@@ -878,9 +937,10 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
             Record<BASIS> rec;
             load_record<BASIS>(p, it_leaf[jmine], rec);
             if (HAS_BASIS) {  // runtime basis size: first coefficient of each channel only
-                r0 = weight / (1.f + vr_expf(-(b[0] * rec.at(0))));
-                r1 = weight / (1.f + vr_expf(-(b[0] * rec.at(1))));
-                r2 = weight / (1.f + vr_expf(-(b[0] * rec.at(2))));
+                const float b0 = basis_of(0);
+                r0 = weight / (1.f + vr_expf(-(b0 * rec.at(0))));
+                r1 = weight / (1.f + vr_expf(-(b0 * rec.at(1))));
+                r2 = weight / (1.f + vr_expf(-(b0 * rec.at(2))));
             } else {  // RGBA: out[c] = madd(colour, weight, out[c]) is formed by the owner
                 r0 = rec.at(0);
                 r1 = rec.at(1);
@@ -1007,6 +1067,11 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                         ray.tmax = u2f(rb[(size_t)10 * cap]);
                         ray.delta_scale = u2f(rb[(size_t)11 * cap]);
                         ray_id = r;
+                        if (HAS_BASIS) {
+#pragma unroll
+                            for (int i = 0; i < NB; ++i)
+                                mybasis[i] = u2f(rb[(size_t)(kRayWords + i) * cap]);
+                        }
                         ray.out[0] = ray.out[1] = ray.out[2] = ray.out[3] = 0.f;
                         ray.light = 1.f;
                         ray.active = ray.alive = ray.entered = true;
