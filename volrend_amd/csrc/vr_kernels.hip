@@ -30,7 +30,14 @@ constexpr int kWave = 64;
 #define VR_MIN_WAVES_PER_EU 8  // cap on the per-flavour register bounds (experiments)
 #endif
 #ifndef VR_SH16_ROWS
-#define VR_SH16_ROWS 56  // SH16 items per shade round (64: one more LDS granule, 20 waves per CU)
+#define VR_SH16_ROWS 64  // SH16 items per shade round (56 fits 24 waves per CU into the LDS, but
+                         // measured slower: 0.275 against 0.265 ms per C1 frame)
+#endif
+#ifndef VR_SHADE_SCHED_BARRIER
+#define VR_SHADE_SCHED_BARRIER 0
+#endif
+#ifndef VR_SH16_WAVES
+#define VR_SH16_WAVES 5
 #endif
 constexpr int kMaxIter = 1 << 22;  // guard against step_size <= 0 (upstream would spin forever)
 
@@ -424,9 +431,11 @@ struct GroupWin {
 template <int FMA, int BASIS, int LO, int HI, typename GET>
 __device__ __forceinline__ void add_group(const char* row, GET&& get, float* acc) {
     float b[VR_MAX_BASIS];
-    // keep the scheduler from hoisting the next group's fetches over this group's arithmetic:
-    // that is the register saving
+#if VR_SHADE_SCHED_BARRIER
+    // keeps the scheduler from hoisting the next group's fetches over this group's arithmetic
+    // (lowest register use, but every group then waits for its own LDS round trip)
     __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int i = LO; i <= HI; ++i) b[i] = get(i);
     {
@@ -778,7 +787,7 @@ typedef std::conditional<(VR_OWNER_Q > 4), uint64_t, uint32_t>::type qpos_t;
 template <int BASIS, int MODE>
 constexpr int min_waves_per_eu() {
     if (MODE != MODE_FAST) return 4;
-    const int want = BASIS == BASIS_25 ? 4 : BASIS == BASIS_16 ? 6 : BASIS == BASIS_9 ? 7 : 8;
+    const int want = BASIS == BASIS_25 ? 4 : BASIS == BASIS_16 ? VR_SH16_WAVES : BASIS == BASIS_9 ? 7 : 8;
     return want < VR_MIN_WAVES_PER_EU ? want : VR_MIN_WAVES_PER_EU;
 }
 // Waves one CU holds of a flavour: the register bound above or the LDS bound (512-byte granules).
@@ -933,11 +942,12 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     TL_ADD(tl_shade_math);
                 }
             }
-        } else if (have) {
+        } else {
+          const float b0 = HAS_BASIS ? basis_of(0) : 0.f;  // (every lane: see above)
+          if (have) {
             Record<BASIS> rec;
             load_record<BASIS>(p, it_leaf[jmine], rec);
             if (HAS_BASIS) {  // runtime basis size: first coefficient of each channel only
-                const float b0 = basis_of(0);
                 r0 = weight / (1.f + vr_expf(-(b0 * rec.at(0))));
                 r1 = weight / (1.f + vr_expf(-(b0 * rec.at(1))));
                 r2 = weight / (1.f + vr_expf(-(b0 * rec.at(2))));
@@ -946,6 +956,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 r1 = rec.at(1);
                 r2 = rec.at(2);
             }
+          }
         }
         __syncthreads();  // every row has been read: `res` may overwrite them
         if (have) {
