@@ -9,7 +9,7 @@ ROCM ?= /opt/rocm
 PKG = volrend_amd
 HOST = $(PKG)/csrc/host
 HOST_SRC = $(HOST)/npz.cpp $(HOST)/n3tree.cpp $(HOST)/camera.cpp $(HOST)/opts.cpp \
-           $(HOST)/imwrite.cpp $(HOST)/renderer.cpp
+           $(HOST)/imwrite.cpp $(HOST)/renderer.cpp $(HOST)/tile_shard.cpp
 HOST_OBJ = $(HOST_SRC:.cpp=.o)
 CXXFLAGS = -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude
 
@@ -21,6 +21,10 @@ lib:
 $(HOST)/%.o: $(HOST)/%.cpp
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
+# the multi-GPU tile shard talks to the HIP runtime and RCCL directly
+$(HOST)/tile_shard.o: $(HOST)/tile_shard.cpp include/volrend/internal/tile_shard.hpp
+	$(CXX) $(CXXFLAGS) -I$(ROCM)/include -D__HIP_PLATFORM_AMD__ -c $< -o $@
+
 host: $(PKG)/libvolrend_host.a
 $(PKG)/libvolrend_host.a: $(HOST_OBJ)
 	ar rcs $@ $(HOST_OBJ)
@@ -30,7 +34,7 @@ $(PKG)/bin/volrend_headless: $(HOST)/main_headless.cpp $(PKG)/libvolrend_host.a 
 	mkdir -p $(PKG)/bin
 	$(CXX) -O2 -std=c++17 -Iinclude -I$(ROCM)/include -D__HIP_PLATFORM_AMD__ \
 	  $(HOST)/main_headless.cpp $(PKG)/libvolrend_host.a -L$(PKG) -lvolrend_hip \
-	  -L$(ROCM)/lib -lamdhip64 -lz -pthread -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,$(ROCM)/lib -o $@
+	  -L$(ROCM)/lib -lrccl -lamdhip64 -lz -pthread -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,$(ROCM)/lib -o $@
 
 oracle:
 	$(MAKE) -C oracle

@@ -124,12 +124,36 @@ def cpu_baseline(tree, transforms, width, height, focal, budget_s=8.0):
     return out
 
 
+def rtfrag_baseline(timeout_s=240):
+    """BASELINE config C0 next to the GPU number (north_star): the reference's GLSL backend
+    (shaders/rt.frag, its no-CUDA shader_renderer path) on a software GL rasteriser on THIS
+    box's host cores -- Mesa llvmpipe when the box has Mesa EGL, else SwiftShader, named in the
+    result.  One 400x400 C0 frame after a warm-up frame, in a child process
+    (oracle/ref_build/rtfrag_baseline.py; baseline infrastructure, never the product)."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "ref_build", "rtfrag_baseline.py"),
+           "--config", "C0", "--frames", "2"]
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s,
+                             cwd=ROOT)
+        if out.returncode != 0:
+            return {"error": out.stderr.decode(errors="replace").strip().splitlines()[-1][:200]}
+        r = json.loads(out.stdout.decode())
+    except Exception as e:  # baseline only: never fail the bench over it
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+    return {"value": r["rt_frag_mrays_per_s"], "unit": "Mrays/s", "cores": r["cores"],
+            "ms_per_frame": r["rt_frag_ms_per_frame"], "rasteriser": r["rasteriser"],
+            "sample": f"one {r['image'][0]}x{r['image'][1]} frame of C0 ({r['nodes']} nodes, SH16), "
+                      f"pose {r['pose']}, mean of 2 frames after a warm-up frame",
+            "psnr_vs_oracle_db": r["psnr_rt_frag_vs_oracle_db"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--config", default="C1", choices=["C0", "C1", "C2", "C3"])
+    ap.add_argument("--config", default="C1", choices=["C0", "C1", "C1r", "C1t", "C2", "C3"])
     ap.add_argument("--fp", default="strict", choices=["strict", "fma"])
     ap.add_argument("--tile-rows", type=int, default=8, help="rows per interleaved screen tile")
     ap.add_argument("--batch", type=int, default=64,
@@ -313,13 +337,30 @@ def main():
     counters = torch.zeros((B, 7), dtype=torch.int64, device=dev)
     scratch = [torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(B)]
     full = api.TileShard(tile_w, tile_h, s_rank, s_world, compact=False)
+    # B_unique: distinct 128-byte lines of the tree arrays that the accesses of one
+    # launch / one frame touch -- the compulsory-traffic lower bound next to the algorithmic bytes
+    # (distinct-line bitmaps of the instrumented flavour, vr_touch_enable / vr_touch_count)
+    tree.touch_enable(True)
+    unique_launch = None
     jd = 0
     while jd < n_distinct:  # same batching as the timed region
         n = min(B, n_distinct - jd)
         tr = [pose_of(args.warmup + jd + i) for i in range(n)]
         api.launch_renderer_batch(tree, cam, tr, opts, scratch[:n], stream, True, shard=full,
                                   fp_mode=fp_mode, counters=[counters[i] for i in range(n)])
+        if jd == 0:
+            unique_launch = (n, tree.touch_count(reset=True))
         jd += n
+    tree.touch_count(reset=True)
+    unique_frames = []
+    side = torch.zeros((1, 7), dtype=torch.int64, device=dev)
+    for i in range(4):  # four single frames spread over the timed poses
+        tr = [pose_of(args.warmup + (i * n_distinct) // 4)]
+        api.launch_renderer_batch(tree, cam, tr, opts, scratch[:1], stream, True, shard=full,
+                                  fp_mode=fp_mode, counters=[side[0]])
+        unique_frames.append(tree.touch_count(reset=True))
+    tree.touch_enable(False)
+    del side
     torch.cuda.synchronize()
     cnt = dict(zip(_abi.COUNTER_FIELDS, [int(v) for v in counters.sum(dim=0).cpu().tolist()]))
     alg_bytes_per_frame = cnt["alg_bytes"] / n_distinct  # this rank's share of a frame
@@ -374,19 +415,33 @@ def main():
     kern_mean_s = kern_total_s / n_launch
     alg_bytes_per_launch = alg_bytes_per_frame * K / n_launch
 
-    # HBM-side traffic: PMC counters need a rocprofv3 run of their own (tools/pmc.sh), so the
-    # bench reports the committed measurement of the same kernel/config, scaled to this
-    # launch size, and says where it comes from; null when nothing matches.
+    # HBM-side traffic: PMC counters need rocprofv3 runs of their own (tools/measure_traffic.py, one
+    # counter group per pass), so the bench reports the committed measurement of this config,
+    # scaled to this launch size -- but only while the SHA-256 of the kernel sources recorded in
+    # it still matches the sources this run was built from; otherwise null, and the reason.
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if world == 1 and os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("config") == args.config and tj.get("fp_mode") == args.fp:
-            traffic = int((tj["read_bytes_per_frame"] + tj["write_bytes_per_frame"]) *
+    if world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from measure_traffic import kernel_source_hash
+        have = kernel_source_hash()
+        import glob as _glob
+        cands = sorted(_glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{args.config}.json")),
+                       reverse=True)
+        traffic_src = f"no profiles/r*_traffic_{args.config}.json"
+        for tpath in cands:
+            tj = json.load(open(tpath))
+            rel = os.path.relpath(tpath, ROOT)
+            if tj.get("fp_mode") != args.fp or "read_bytes_per_frame" not in tj:
+                continue
+            if tj.get("kernel_source_sha256") != have:
+                traffic_src = f"{rel} is STALE (kernel sources changed since it was measured)"
+                continue
+            traffic = int((tj["read_bytes_per_frame"] + tj.get("write_bytes_per_frame", 0.0)) *
                           K / n_launch)
-            traffic_src = (f"profiles/r01_traffic.json (rocprofv3 --pmc passes at "
-                           f"{tj['frames_per_launch']} frames per launch, TCC_EA0_RDREQ_128B*128 "
-                           f"+ WRITE_SIZE; FETCH_SIZE under-counts this kernel 2x)")
+            traffic_src = (f"{rel}: rocprofv3 --pmc passes at {tj['frames_per_launch']} frames per "
+                           f"launch, TCC_EA0_RDREQ_128B*128 + _64B*64 + _32B*32 + WRITE_SIZE, kernel "
+                           f"source hash verified")
+            break
 
     if rank == 0:
         # replicas: every rank rendered its own K frames; tile mode: the K frames were shared
@@ -442,10 +497,17 @@ def main():
                 "samples_per_ray": round(cnt["samples"] / max(cnt["rays"], 1), 2),
                 "hit_samples_per_ray": round(cnt["hit_samples"] / max(cnt["rays"], 1), 2),
                 "child_words_per_sample": round(cnt["child_reads"] / max(cnt["samples"], 1), 2),
+                # B_unique: distinct 128-byte lines touched in the device arrays (x 128 bytes)
+                "unique_bytes_per_launch": 128 * sum(unique_launch[1].values()),
+                "unique_launch_frames": unique_launch[0],
+                "unique_bytes_per_frame": int(128 * np.mean([sum(u.values()) for u in unique_frames])),
+                "unique_lines_per_frame_by_array": {
+                    k: int(np.mean([u[k] for u in unique_frames])) for k in unique_frames[0]},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(stree, transforms, W, H, focal, args.cpu_budget)
+            result["cpu_baseline"]["rtfrag"] = rtfrag_baseline()
         else:
             result["cpu_baseline"] = None
         os.write(json_fd, (json.dumps(result) + "\n").encode())

@@ -26,8 +26,11 @@
  * Asynchrony matches the reference: vr_render only enqueues on `stream`
  * (a hipStream_t passed as void*, NULL = the null stream) and returns.
  * The library owns device copies of trees; callers own output buffers,
- * streams and events.  One host thread per device, or one thread driving
- * several devices with explicit vr_set_device().
+ * streams and events.  A tree belongs to the device it was uploaded (or cloned)
+ * to; calls that take a tree run on that device whatever the calling thread's
+ * current device is and leave the thread's device unchanged, so one host thread
+ * may drive the trees of several devices.  Streams and buffers passed with a
+ * tree must belong to the tree's device.
  *
  * Launches in flight.  Unlike the reference's launch_renderer, a launch here
  * carries per-launch scratch in device memory (frame table, ray queue, ray
@@ -204,6 +207,11 @@ int vr_tree_upload_quantized(const VrTreeDesc* desc, const VrQuantDesc* quant, v
 /* The decode alone: writes the reference's flat data array [n_slots * data_dim] fp16 to
  * data_out (host or device memory per desc->memory; desc->child/data are not read). */
 int vr_decode_quantized(const VrTreeDesc* desc, const VrQuantDesc* quant, uint16_t* data_out);
+/* A second copy of an uploaded tree on another (or the same) device of this process: the device
+ * layout is copied device to device (hipMemcpyPeer: xGMI between two GPUs of a node), so the
+ * file crosses PCIe and is re-laid-out once however many GPUs render it.  The multi-GPU screen
+ * tile shard (VrFrame.rank / world) renders from one such replica per GPU.  Synchronous. */
+int vr_tree_clone(vr_tree_t src, int device, vr_tree_t* out);
 int vr_tree_free(vr_tree_t tree);
 int vr_tree_info(vr_tree_t tree, VrTreeInfo* info);
 
@@ -238,6 +246,14 @@ int vr_set_tuning(const char* key, int value);
  * [4] distinct leaves summed over shade rounds [5] retire rounds [6] rays retired in them [7] scheduler iterations.
  * Synchronous (copies from the device); reset != 0 clears them. */
 int vr_sched_stats(vr_tree_t tree, uint64_t out[8], int reset);
+/* Distinct-line meter (SURVEY.md 8(d) "B_unique", the compulsory-traffic lower bound): with
+ * enable != 0 the tree gets one bit per 128-byte line of its device arrays, and every
+ * INSTRUMENTED launch (frames with counters) sets the bits of the lines its accesses touch.
+ * vr_touch_count returns the number of distinct lines touched since the last reset in
+ * out[0..3] = coefficient records, child words, top grid, bricks (x 128 = bytes).  Both calls
+ * are synchronous (device-wide).  Production launches never see the bitmaps. */
+int vr_touch_enable(vr_tree_t tree, int enable);
+int vr_touch_count(vr_tree_t tree, uint64_t out[4], int reset);
 /* gathered = world consecutive COMPACT buffers (rank-major), all device memory
  * on the current device.  Writes the W x H frame. */
 int vr_assemble_tiles(void* frame_rgba, int64_t pitch, const void* gathered, int width,

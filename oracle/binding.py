@@ -17,6 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "liboracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libvolrend_ref.so")
 REF_LIBM_SO = os.path.join(HERE, "_ref", "libvolrend_ref_libm.so")
+RTFRAG_GLSL = os.path.join(HERE, "_ref", "rt_frag_es300.glsl")
 REFERENCE_ROOT = "/root/reference"
 
 FP_STRICT, FP_FMA = 0, 1
@@ -68,7 +69,8 @@ def build_ref(force: bool = False) -> str | None:
     read-only reference mount exists (never on the GPU box)."""
     if not os.path.isdir(REFERENCE_ROOT):
         return REF_SO if os.path.exists(REF_SO) else None
-    if force or not os.path.exists(REF_SO) or not os.path.exists(REF_LIBM_SO):
+    if force or not os.path.exists(REF_SO) or not os.path.exists(REF_LIBM_SO) or \
+            not os.path.exists(RTFRAG_GLSL):
         subprocess.check_call(["make", "-C", os.path.join(HERE, "ref_build"), "-B"],
                               stdout=subprocess.DEVNULL)
     return REF_SO

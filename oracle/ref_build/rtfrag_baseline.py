@@ -4,16 +4,19 @@
 
     python oracle/ref_build/rtfrag_baseline.py [--size 400] [--config C0] [--out profiles/...json]
 
-TEST / BASELINE INFRASTRUCTURE.  Runs only where the read-only reference mount exists:
-the fragment shader is read from /root/reference/shaders/rt.frag at run time (never copied
-into this repo) and compiled with the "#version 300 es" prefix the reference itself uses for
-its WebGL build (include/volrend/internal/shader.hpp:42-46).  The harness mirrors what
+TEST / BASELINE INFRASTRUCTURE.  The fragment shader is the reference's own: read from
+/root/reference/shaders/rt.frag where that mount exists, otherwise from the git-ignored build
+artefact oracle/_ref/rt_frag_es300.glsl that oracle/ref_build/Makefile generates from it (so the
+baseline can also be timed on the GPU box's host cores); never part of this repo's history.
+It is compiled with the "#version 300 es" prefix the reference itself uses for its WebGL build
+(include/volrend/internal/shader.hpp:42-46).  The harness mirrors what
 src/shader_renderer.cpp does around it: tree packed into an R16F and an R32I 2-D texture
 (:263-342), uniforms (:344-368, :178-190), one full-screen triangle strip (:206-207).
 
-Rasteriser: SwiftShader (GLES 3.0 over EGL pbuffers) as bundled with the `kaleido` wheel --
-the only software GL that creates a context in these containers (no X server / Mesa EGL /
-OSMesa, so Mesa llvmpipe cannot be used).  Reports ms per frame, Mrays/s,
+Rasteriser: Mesa llvmpipe through the system libEGL (surfaceless platform) when that creates a
+GLES 3 context; otherwise SwiftShader (GLES 3.0 over EGL pbuffers) as bundled with the
+`kaleido` wheel -- the only software GL that creates a context in these containers (no X
+server / Mesa EGL / OSMesa).  The result names the rasteriser that ran.  Reports ms per frame, Mrays/s,
 the host core count, and PSNR of the frame against the CPU oracle (the CUDA-path
 semantics): a cross-check of the oracle against the reference's OTHER backend.
 """
@@ -31,7 +34,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-REF = "/root/reference"
+REF = os.environ.get("VOLREND_REFERENCE", "/root/reference")
 
 EGL_NONE, EGL_SURFACE_TYPE, EGL_PBUFFER_BIT = 0x3038, 0x3033, 0x0001
 EGL_RENDERABLE_TYPE, EGL_OPENGL_ES3_BIT = 0x3040, 0x0040
@@ -59,13 +62,36 @@ def find_swiftshader():
     return None
 
 
+def find_mesa():
+    """System Mesa EGL + GLES (llvmpipe), if installed: (libEGL path, libGLESv2 path) or None."""
+    import ctypes.util
+    egl, gles = ctypes.util.find_library("EGL"), ctypes.util.find_library("GLESv2")
+    return (egl, gles) if egl and gles else None
+
+
 class GL:
-    def __init__(self, width, height):
+    def __init__(self, width, height, prefer="auto"):
+        mesa = find_mesa() if prefer in ("auto", "mesa") else None
+        if mesa is not None:
+            try:
+                os.environ.setdefault("EGL_PLATFORM", "surfaceless")
+                os.environ.setdefault("LIBGL_ALWAYS_SOFTWARE", "1")
+                os.environ.setdefault("LP_NUM_THREADS", str(os.cpu_count() or 1))
+                self._open(mesa[1], mesa[0], width, height)
+                self.stack = "Mesa EGL (surfaceless)"
+                return
+            except (OSError, RuntimeError):
+                if prefer == "mesa":
+                    raise
         d = find_swiftshader()
         if d is None:
-            raise RuntimeError("no software GL (SwiftShader) found")
-        self.gles = C.CDLL(os.path.join(d, "libGLESv2.so"), mode=C.RTLD_GLOBAL)
-        self.egl = C.CDLL(os.path.join(d, "libEGL.so"), mode=C.RTLD_GLOBAL)
+            raise RuntimeError("no software GL (Mesa EGL or SwiftShader) found")
+        self._open(os.path.join(d, "libGLESv2.so"), os.path.join(d, "libEGL.so"), width, height)
+        self.stack = "SwiftShader EGL pbuffer"
+
+    def _open(self, gles_path, egl_path, width, height):
+        self.gles = C.CDLL(gles_path, mode=C.RTLD_GLOBAL)
+        self.egl = C.CDLL(egl_path, mode=C.RTLD_GLOBAL)
         e = self.egl
         e.eglGetDisplay.restype = C.c_void_p
         e.eglGetDisplay.argtypes = [C.c_void_p]
@@ -171,10 +197,18 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="override the square image size")
     ap.add_argument("--pose", type=int, default=0)
     ap.add_argument("--out", default="")
+    ap.add_argument("--rasteriser", default="auto", choices=["auto", "mesa", "swiftshader"])
+    ap.add_argument("--frames", type=int, default=1, help="timed frames after the warm-up frame")
     args = ap.parse_args()
     frag_path = os.path.join(REF, "shaders", "rt.frag")
-    if not os.path.exists(frag_path):
-        raise SystemExit("needs the reference mount (shaders/rt.frag is read at run time)")
+    built = os.path.join(ROOT, "oracle", "_ref", "rt_frag_es300.glsl")
+    if os.path.exists(frag_path):
+        frag = b"#version 300 es\n" + open(frag_path, "rb").read()
+    elif os.path.exists(built):
+        frag = open(built, "rb").read()
+    else:
+        raise SystemExit("needs the reference's rt.frag: the reference mount, or oracle/_ref/"
+                         "rt_frag_es300.glsl generated by build() where the mount exists")
     from oracle import binding as ob
     from volrend_amd import synth
 
@@ -184,7 +218,7 @@ def main():
     tree = synth.make_config_tree(args.config)
     n_slots = tree.capacity * 8
     dd = tree.data_dim
-    gl = GL(W, H)
+    gl = GL(W, H, args.rasteriser)
     g = gl.gles
     mx = C.c_int()
     g.glGetIntegerv(GL_MAX_TEXTURE_SIZE, C.byref(mx))
@@ -193,7 +227,6 @@ def main():
     if max(dw, dh, cw, ch) > mx.value:
         raise SystemExit(f"tree exceeds GL_MAX_TEXTURE_SIZE={mx.value}")
 
-    frag = b"#version 300 es\n" + open(frag_path, "rb").read()
     prog = gl.program(VERT_SRC, frag)
     loc = lambda n: g.glGetUniformLocation(prog, n.encode())  # noqa: E731
 
@@ -253,8 +286,9 @@ def main():
     draw()  # warm-up: includes the rasteriser's shader JIT
     t_warm = time.perf_counter() - t0
     t0 = time.perf_counter()
-    draw()
-    t_frame = time.perf_counter() - t0
+    for _ in range(max(1, args.frames)):
+        draw()
+    t_frame = (time.perf_counter() - t0) / max(1, args.frames)
     img = np.zeros((H, W, 4), dtype=np.uint8)
     g.glPixelStorei(GL_PACK_ALIGNMENT, 1)
     g.glReadPixels(0, 0, W, H, GL_RGBA, GL_UNSIGNED_BYTE, img.ctypes.data)
@@ -270,7 +304,8 @@ def main():
     d = np.abs(img[..., :3].astype(int) - ref[..., :3].astype(int))
     result = {
         "config": args.config, "image": [W, H], "pose": args.pose, "nodes": tree.capacity,
-        "rasteriser": f"SwiftShader ({gl.renderer}; {gl.version}) via EGL pbuffer -- not Mesa llvmpipe",
+        "rasteriser": f"{gl.renderer}; {gl.version}; {gl.stack}" + (
+            "" if "llvmpipe" in gl.renderer.lower() else " -- not Mesa llvmpipe"),
         "cores": os.cpu_count(),
         "rt_frag_ms_per_frame": round(t_frame * 1e3, 2),
         "rt_frag_mrays_per_s": round(W * H / t_frame / 1e6, 4),

@@ -36,9 +36,18 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     roof = d["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3)
+    # B_unique next to the algorithmic bytes (distinct 128-byte lines)
+    assert 0 < roof["unique_bytes_per_frame"] and 0 < roof["unique_bytes_per_launch"]
+    assert roof["unique_bytes_per_launch"] <= roof["unique_bytes_per_frame"] * roof["unique_launch_frames"] * 1.5
+    assert set(roof["unique_lines_per_frame_by_array"]) == {"leaves", "nodes", "top", "bricks"}
+    # no committed traffic measurement for C0: null, with the reason
+    assert roof["traffic"] is None and roof["traffic_source"]
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     assert cb["sample"] and (cb["kind"] == "port" or cb["port"]["value"] > 0)
+    # the reference's GLSL backend on a software rasteriser, same box (or the reason it could not run)
+    assert "rtfrag" in cb and ("error" in cb["rtfrag"] or (
+        cb["rtfrag"]["value"] > 0 and cb["rtfrag"]["cores"] >= 1 and cb["rtfrag"]["rasteriser"]))
 
 
 @pytest.mark.parametrize("mode", ["tile", "replicas"])

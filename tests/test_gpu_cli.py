@@ -102,3 +102,42 @@ def test_headless_cli_quantised_tree(cli, tmp_path):
     cam = ob.make_camera(synth.c2w_to_transform(pose), 64, 64, 90.0)
     want, _, _ = ob.render(ob.TreeHandle(tree), cam, ob.default_options(), want_accum=False)
     assert np.array_equal(img, want)
+
+
+def test_headless_cli_tile_shard(cli, tmp_path):
+    """--gpus N: interleaved screen tiles, one tree replica per rank (vr_tree_clone), gather to
+    the root, batch assembly -- must write the same PNGs as the oracle.  On this one-GPU box:
+    --gpus 1 goes through RCCL (ncclCommInitAll + a grouped self send/recv), --gpus 2/3 with
+    --share_gpu rehearse the N-rank bookkeeping on one device; with >= 2 GPUs visible the real
+    2-rank RCCL path runs as well."""
+    import torch
+    from PIL import Image
+    tree = common.small_scene(depth=5, basis_dim=9, seed=404)
+    npz = str(tmp_path / "tree.npz")
+    synth.save_npz(tree, npz)
+    poses = synth.make_poses(8)[:7]
+    w, h, focal = 100, 76, 120.0     # neither a multiple of the tile size
+    paths = synth.write_pose_dir(str(tmp_path), poses, w, focal)
+    th = ob.TreeHandle(tree)
+    want = [ob.render(th, ob.make_camera(synth.c2w_to_transform(p), w, h, focal),
+                      ob.default_options(), want_accum=False)[0] for p in poses]
+    runs = [(["--gpus", "1"], "RCCL"),
+            (["--gpus", "2", "--share_gpu"], "REHEARSAL"),
+            (["--gpus", "3", "--share_gpu", "--tile", "16"], "REHEARSAL")]
+    if torch.cuda.device_count() >= 2:
+        runs.append((["--gpus", "2"], "RCCL"))
+    for k, (flags, label) in enumerate(runs):
+        out_dir = str(tmp_path / f"o{k}")
+        r = subprocess.run([cli, npz, *paths, "-w", str(w), "-h", str(h), "--fx", str(focal), "-o",
+                            out_dir, "--batch", "3", *flags], capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert "screen-tile shard" in r.stdout and label in r.stdout, r.stdout
+        assert re.search(r"\d+\.\d{10} fps", r.stdout)
+        for i in range(len(poses)):
+            img = np.asarray(Image.open(os.path.join(out_dir, f"{i:04d}.png")))
+            assert np.array_equal(img, want[i]), (flags, i)
+    if torch.cuda.device_count() < 2:  # more ranks than GPUs without --share_gpu: a clean error
+        r = subprocess.run([cli, npz, paths[0], "-w", "64", "-h", "64", "--gpus", "2"],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "need more GPUs" in r.stderr

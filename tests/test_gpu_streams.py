@@ -78,3 +78,38 @@ def test_reserve_status_and_step_size(torch_cuda):
     rgba_o, _, _ = common.oracle_frame(tree, tr, w, h, f, 0)
     assert np.array_equal(img.cpu().numpy(), rgba_o)
     t.free_device()
+
+
+def test_tree_clone_renders_the_same_frames(torch_cuda):
+    """vr_tree_clone: the device-to-device replica (here onto the same device -- the box has one)
+    renders bit for bit what the original renders, both stay usable side by side, and freeing
+    one leaves the other intact."""
+    torch = torch_cuda
+    from volrend_amd import api
+    tree = common.small_scene(depth=6, basis_dim=16, seed=414)
+    t = api.N3Tree.from_synth(tree)
+    r = t.clone_to(0)
+    assert r.info()["device_bytes"] == t.info()["device_bytes"] and r.info()["device"] == 0
+    tr, w, h, f = common.camera_for(pose_idx=2, size=104)
+    cam = api.Camera(w, h, f, f)
+    rgba_o, acc_o, _ = common.oracle_frame(tree, tr, w, h, f, 0)
+    imgs = torch.zeros((2, h, w, 4), dtype=torch.uint8, device="cuda")
+    accs = torch.zeros((2, h, w, 4), dtype=torch.float32, device="cuda")
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    for k, (tt, st) in enumerate(((t, s0), (r, s1))):
+        with torch.cuda.stream(st):
+            api.launch_renderer_batch(tt, cam, [tr], api.RenderOptions(), [imgs[k]], st, True,
+                                      accums=[accs[k]])
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert np.array_equal(imgs[k].cpu().numpy(), rgba_o)
+        assert np.array_equal(accs[k].cpu().numpy().view(np.uint32), acc_o.view(np.uint32))
+    t.free_device()
+    img = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    api.launch_renderer_batch(r, cam, [tr], api.RenderOptions(), [img], torch.cuda.current_stream(),
+                              True)
+    torch.cuda.synchronize()
+    assert np.array_equal(img.cpu().numpy(), rgba_o)
+    with pytest.raises(api._abi.VolrendError):
+        r.clone_to(99)
+    r.free_device()

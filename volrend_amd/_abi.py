@@ -82,6 +82,7 @@ PROTOTYPES = {
     "vr_tree_upload_quantized": (C.c_int, [C.POINTER(VrTreeDesc), C.POINTER(VrQuantDesc),
                                            C.POINTER(C.c_void_p)]),
     "vr_decode_quantized": (C.c_int, [C.POINTER(VrTreeDesc), C.POINTER(VrQuantDesc), C.c_void_p]),
+    "vr_tree_clone": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "vr_tree_free": (C.c_int, [C.c_void_p]),
     "vr_tree_info": (C.c_int, [C.c_void_p, C.POINTER(VrTreeInfo)]),
     "vr_default_options": (None, [C.POINTER(VrRenderOptions)]),
@@ -95,6 +96,8 @@ PROTOTYPES = {
     "vr_tree_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "vr_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "vr_sched_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 8), C.c_int]),
+    "vr_touch_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "vr_touch_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 4), C.c_int]),
     "vr_assemble_tiles": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_void_p]),
     "vr_assemble_tiles_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,

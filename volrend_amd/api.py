@@ -286,6 +286,20 @@ class N3Tree:
                                             a["data_retained"], self.data_dim).reshape(shape)
         return self.data_
 
+    def clone_to(self, device: int) -> "N3Tree":
+        """A replica of the DEVICE copy on another (or the same) device of this process
+        (vr_tree_clone: device-to-device, no second upload / re-layout).  The replica shares the
+        host-side metadata and owns its device copy."""
+        t = N3Tree()
+        for k in ("N", "data_dim", "data_format", "capacity", "scale", "offset", "use_ndc",
+                  "ndc_width", "ndc_height", "ndc_focal", "child_"):
+            setattr(t, k, getattr(self, k))
+        h = C.c_void_p()
+        _abi.check(_abi.lib().vr_tree_clone(self.handle, int(device), C.byref(h)))
+        t._handle = h
+        t._loaded = True
+        return t
+
     def free_device(self) -> None:
         if self._handle:
             _abi.lib().vr_tree_free(self._handle)
@@ -307,6 +321,16 @@ class N3Tree:
         names = ("march_rounds", "march_lanes", "shade_rounds", "shade_lanes", "distinct_leaves",
                  "retire_rounds", "retired", "iterations")
         return dict(zip(names, [int(v) for v in out]))
+
+    def touch_enable(self, enable: bool = True) -> None:
+        """Distinct-line meter of instrumented launches on / off (vr_touch_enable)."""
+        _abi.check(_abi.lib().vr_touch_enable(self.handle, 1 if enable else 0))
+
+    def touch_count(self, reset: bool = True) -> dict:
+        """Distinct 128-byte lines touched since the last reset (vr_touch_count), per array."""
+        out = (C.c_uint64 * 4)()
+        _abi.check(_abi.lib().vr_touch_count(self.handle, C.byref(out), 1 if reset else 0))
+        return dict(zip(("leaves", "nodes", "top", "bricks"), [int(v) for v in out]))
 
     def reserve(self, width: int, height: int, n_frames: int) -> None:
         """Pre-allocate the per-launch ray buffers (vr_reserve): no later launch of that

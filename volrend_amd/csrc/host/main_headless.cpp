@@ -23,6 +23,7 @@
 
 #include "volrend/internal/imwrite.hpp"
 #include "volrend/internal/opts.hpp"
+#include "volrend/internal/tile_shard.hpp"
 #include "volrend/n3tree.hpp"
 #include "volrend/renderer_kernel.hpp"
 
@@ -172,7 +173,14 @@ int main(int argc, char* argv[]) {
     args.add("reverse_yz", 'r', true, "", "use OpenCV camera space convention instead of NeRF");
     args.add("scale", 0, false, "1.0", "scaling to apply to image");
     args.add("max_imgs", 0, false, "0", "max images to render, default no limit");
-    args.add("batch", 0, false, "32", "poses per launch (1..128)");
+    args.add("batch", 0, false, "32", "poses per launch (1..512)");
+    args.add("gpus", 0, false, "0",
+             "render every frame on this many GPUs (devices --gpu .. --gpu+N-1): interleaved "
+             "screen tiles, tree replicated device to device, RCCL gather of the RGBA8 tiles to "
+             "the first GPU; 0 = plain single-GPU path");
+    args.add("tile", 0, false, "8", "rows per screen tile of the --gpus shard (multiple of 8)");
+    args.add("share_gpu", 0, true, "",
+             "REHEARSAL of --gpus N on a box with fewer GPUs: all ranks on one device, no RCCL");
     args.add("fp", 0, false, "strict", "floating-point model: strict | fma");
     args.add("dump_poses", 0, true, "", "print the parsed poses / intrinsics and exit (no GPU needed)");
     args.add("host_decode", 0, true, "",
@@ -275,8 +283,39 @@ int main(int argc, char* argv[]) {
     const int fp_mode = args.str("fp") == "fma" ? VR_FP_FMA : VR_FP_STRICT;
 
     const size_t frame_bytes = (size_t)width * height * 4;
-    std::vector<void*> images(batch);
-    for (int i = 0; i < batch; ++i) HIP_OK(hipMalloc(&images[i], frame_bytes));
+    const int n_gpus = args.as_int("gpus");
+    const RenderOptions options = internal::render_options_from_args(args);
+    VrRenderOptions copt;
+    vr_default_options(&copt);
+    copt.step_size = options.step_size;
+    copt.sigma_thresh = options.sigma_thresh;
+    copt.stop_thresh = options.stop_thresh;
+    copt.background_brightness = options.background_brightness;
+
+    // --gpus N: the frames of a launch are rendered tile-sharded on N devices and assembled on
+    // the first one (include/volrend/internal/tile_shard.hpp); otherwise one device renders
+    // whole frames.  Either way `images[i]` below is frame i of the current launch on `out_dev`.
+    std::unique_ptr<internal::TileShardRenderer> shard;
+    if (n_gpus >= 1) {
+        internal::TileShardConfig sc;
+        sc.n_ranks = n_gpus;
+        sc.first_device = device_id >= 0 ? device_id : 0;
+        sc.share_device = args.as_bool("share_gpu");
+        sc.tile_rows = args.as_int("tile");
+        sc.max_batch = batch;
+        try {
+            shard.reset(new internal::TileShardRenderer(tree, width, height, sc));
+        } catch (const std::exception& e) {
+            fprintf(stderr, "ERROR: %s\n", e.what());
+            return 1;
+        }
+        printf("INFO: %d-way screen-tile shard, %d-row tiles, %s\n", n_gpus,
+               sc.tile_rows < 8 ? 8 : sc.tile_rows / 8 * 8, shard->transport().c_str());
+        HIP_OK(hipSetDevice(shard->root_device()));
+    }
+    std::vector<void*> images(batch, nullptr);
+    if (!shard)
+        for (int i = 0; i < batch; ++i) HIP_OK(hipMalloc(&images[i], frame_bytes));
     uint8_t* host_sets[2] = {nullptr, nullptr};  // pinned, one per in-flight batch
     std::unique_ptr<EncodePool> pool;
     if (!out_dir.empty()) {
@@ -287,23 +326,18 @@ int main(int argc, char* argv[]) {
         pool.reset(new EncodePool(nt));
     }
     hipStream_t stream;
-    HIP_OK(hipStreamCreate(&stream));
+    if (shard) stream = static_cast<hipStream_t>(shard->out_stream());
+    else HIP_OK(hipStreamCreate(&stream));
     hipEvent_t start, stop;
     HIP_OK(hipEventCreate(&start));
     HIP_OK(hipEventCreate(&stop));
-    const RenderOptions options = internal::render_options_from_args(args);
-    VrRenderOptions copt;
-    vr_default_options(&copt);
-    copt.step_size = options.step_size;
-    copt.sigma_thresh = options.sigma_thresh;
-    copt.stop_thresh = options.stop_thresh;
-    copt.background_brightness = options.background_brightness;
 
     HIP_OK(hipEventRecord(start, stream));
-    for (size_t first = 0; first < trans.size(); first += batch) {
+    int seq = 0;
+    for (size_t first = 0; first < trans.size(); first += batch, ++seq) {
         const int n = (int)std::min<size_t>(batch, trans.size() - first);
-        VrCamera cams[VR_MAX_BATCH];
-        VrFrame frames[VR_MAX_BATCH];
+        std::vector<VrCamera> cams((size_t)n);
+        std::vector<VrFrame> frames((size_t)n);
         for (int i = 0; i < n; ++i) {
             const float* m = glm::value_ptr(trans[first + i]);
             for (int k = 0; k < 12; ++k) cams[i].transform[k] = m[k];
@@ -316,12 +350,21 @@ int main(int argc, char* argv[]) {
             frames[i].offscreen = 1;
             frames[i].fp_mode = fp_mode;
         }
-        if (vr_render_batch(tree.device, n, cams, &copt, frames, stream) != VR_OK) {
+        if (shard) {
+            try {
+                shard->render(seq, cams.data(), n, copt, fp_mode);
+            } catch (const std::exception& e) {
+                fprintf(stderr, "ERROR: %s\n", e.what());
+                return 1;
+            }
+            for (int i = 0; i < n; ++i) images[i] = shard->frames(seq & 1) + frame_bytes * i;
+        } else if (vr_render_batch(tree.device, n, cams.data(), &copt, frames.data(), stream) !=
+                   VR_OK) {
             fprintf(stderr, "ERROR: %s\n", vr_last_error());
             return 1;
         }
         if (!out_dir.empty()) {
-            const int set = (int)((first / batch) & 1);
+            const int set = seq & 1;
             pool->wait(set);  // the encoders are done with this buffer set
             for (int i = 0; i < n; ++i) {
                 if (vr_read_back(host_sets[set] + frame_bytes * i, images[i], 0, width, height,
@@ -349,6 +392,7 @@ int main(int argc, char* argv[]) {
     }
     HIP_OK(hipEventRecord(stop, stream));
     HIP_OK(hipEventSynchronize(stop));
+    if (shard) shard->sync();
     float milliseconds = 0;
     HIP_OK(hipEventElapsedTime(&milliseconds, start, stop));
     milliseconds = milliseconds / trans.size();
@@ -360,7 +404,10 @@ int main(int argc, char* argv[]) {
     pool.reset();
     for (auto& hs : host_sets)
         if (hs) HIP_OK(hipHostFree(hs));
-    for (void* p : images) HIP_OK(hipFree(p));
-    HIP_OK(hipStreamDestroy(stream));
+    if (!shard) {
+        for (void* p : images) HIP_OK(hipFree(p));
+        HIP_OK(hipStreamDestroy(stream));
+    }
+    shard.reset();
     return 0;
 }

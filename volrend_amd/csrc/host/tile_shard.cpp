@@ -1,0 +1,220 @@
+// tile_shard.cpp -- see include/volrend/internal/tile_shard.hpp.
+#include "volrend/internal/tile_shard.hpp"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <stdexcept>
+
+namespace volrend {
+namespace internal {
+namespace {
+
+void hip_ok(hipError_t e, const char* what) {
+    if (e != hipSuccess)
+        throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+void nccl_ok(ncclResult_t r, const char* what) {
+    if (r != ncclSuccess)
+        throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r));
+}
+void vr_ok(int rc, const char* what) {
+    if (rc != VR_OK) throw std::runtime_error(std::string(what) + ": " + vr_last_error());
+}
+hipStream_t hs(void* s) { return static_cast<hipStream_t>(s); }
+hipEvent_t he(void* e) { return static_cast<hipEvent_t>(e); }
+ncclComm_t nc(void* c) { return static_cast<ncclComm_t>(c); }
+
+}  // namespace
+
+TileShardRenderer::TileShardRenderer(const N3Tree& tree, int width, int height,
+                                     const TileShardConfig& cfg)
+    : n_(cfg.n_ranks < 1 ? 1 : cfg.n_ranks),
+      width_(width),
+      height_(height),
+      tile_w_((width + 7) / 8 * 8),
+      tile_h_(cfg.tile_rows < 8 ? 8 : cfg.tile_rows / 8 * 8),
+      max_batch_(cfg.max_batch < 1 ? 1 : (cfg.max_batch > VR_MAX_BATCH ? VR_MAX_BATCH : cfg.max_batch)),
+      share_(cfg.share_device && n_ > 1),
+      rccl_self_(n_ == 1) {
+    if (!tree.device) throw std::runtime_error("TileShardRenderer: the tree is not on a device");
+    int n_dev = 0;
+    hip_ok(hipGetDeviceCount(&n_dev), "hipGetDeviceCount");
+    for (int r = 0; r < n_; ++r) device_.push_back(share_ ? cfg.first_device : cfg.first_device + r);
+    if (cfg.first_device < 0 || device_.back() >= n_dev)
+        throw std::runtime_error("TileShardRenderer: " + std::to_string(n_) + " ranks from device " +
+                                 std::to_string(cfg.first_device) + " need more GPUs than the " +
+                                 std::to_string(n_dev) + " visible (--share_gpu rehearses on one)");
+    compact_bytes_ = vr_compact_bytes(width_, height_, tile_w_, tile_h_, n_);
+    if (compact_bytes_ <= 0) throw std::runtime_error("TileShardRenderer: bad tile geometry");
+
+    int prev = 0;
+    hip_ok(hipGetDevice(&prev), "hipGetDevice");
+    VrTreeInfo info;
+    vr_ok(vr_tree_info(tree.device, &info), "vr_tree_info");
+    tree_.assign(n_, nullptr);
+    owns_tree_.assign(n_, false);
+    render_stream_.assign(n_, nullptr);
+    comm_stream_.assign(n_, nullptr);
+    for (int s = 0; s < 2; ++s) {
+        rendered_[s].assign(n_, nullptr);
+        released_[s].assign(n_, nullptr);
+        released_used_[s].assign(n_, false);
+        compact_[s].assign(n_, nullptr);
+    }
+    for (int r = 0; r < n_; ++r) {
+        hip_ok(hipSetDevice(device_[r]), "hipSetDevice");
+        // one replica per rank; the caller's copy serves the root when it already lives there
+        if (r == 0 && info.device == device_[0]) {
+            tree_[r] = tree.device;
+        } else {
+            vr_ok(vr_tree_clone(tree.device, device_[r], &tree_[r]), "vr_tree_clone");
+            owns_tree_[r] = true;
+        }
+        vr_ok(vr_reserve(tree_[r], width_, height_, max_batch_), "vr_reserve");
+        hipStream_t st;
+        hip_ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+        render_stream_[r] = st;
+        hip_ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+        comm_stream_[r] = st;
+        for (int s = 0; s < 2; ++s) {
+            hipEvent_t ev;
+            hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+            rendered_[s][r] = ev;
+            hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+            released_[s][r] = ev;
+            if (r > 0 || rccl_self_)
+                hip_ok(hipMalloc((void**)&compact_[s][r], (size_t)compact_bytes_ * max_batch_),
+                       "hipMalloc(compact)");
+        }
+    }
+    hip_ok(hipSetDevice(device_[0]), "hipSetDevice");
+    for (int s = 0; s < 2; ++s) {
+        hip_ok(hipMalloc((void**)&gather_[s], (size_t)compact_bytes_ * max_batch_ * n_),
+               "hipMalloc(gather)");
+        hip_ok(hipMalloc((void**)&frames_[s], frame_bytes() * max_batch_), "hipMalloc(frames)");
+    }
+    if (!share_) {
+        std::vector<ncclComm_t> comms(n_);
+        nccl_ok(ncclCommInitAll(comms.data(), n_, device_.data()), "ncclCommInitAll");
+        for (auto c : comms) comm_.push_back(c);
+        int ver = 0;
+        ncclGetVersion(&ver);
+        transport_ = "RCCL " + std::to_string(ver) + ", " + std::to_string(n_) +
+                     (n_ == 1 ? " rank (self send/recv)" : " ranks, grouped send/recv to the root");
+    } else {
+        transport_ = "REHEARSAL: " + std::to_string(n_) + " ranks share device " +
+                     std::to_string(device_[0]) + ", tiles move with hipMemcpyAsync (no RCCL)";
+    }
+    hip_ok(hipSetDevice(prev), "hipSetDevice");
+}
+
+TileShardRenderer::~TileShardRenderer() {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (int r = 0; r < n_; ++r) {
+        (void)hipSetDevice(device_[r]);
+        (void)hipDeviceSynchronize();
+    }
+    for (void* c : comm_) (void)ncclCommDestroy(nc(c));
+    for (int r = 0; r < n_; ++r) {
+        (void)hipSetDevice(device_[r]);
+        for (int s = 0; s < 2; ++s) {
+            if (compact_[s][r]) (void)hipFree(compact_[s][r]);
+            if (rendered_[s][r]) (void)hipEventDestroy(he(rendered_[s][r]));
+            if (released_[s][r]) (void)hipEventDestroy(he(released_[s][r]));
+        }
+        if (render_stream_[r]) (void)hipStreamDestroy(hs(render_stream_[r]));
+        if (comm_stream_[r]) (void)hipStreamDestroy(hs(comm_stream_[r]));
+        if (owns_tree_[r] && tree_[r]) (void)vr_tree_free(tree_[r]);
+    }
+    (void)hipSetDevice(device_[0]);
+    for (int s = 0; s < 2; ++s) {
+        if (gather_[s]) (void)hipFree(gather_[s]);
+        if (frames_[s]) (void)hipFree(frames_[s]);
+    }
+    (void)hipSetDevice(prev);
+}
+
+void TileShardRenderer::render(int seq, const VrCamera* cams, int n, const VrRenderOptions& opt,
+                               int fp_mode) {
+    if (n < 1 || n > max_batch_) throw std::invalid_argument("TileShardRenderer::render: batch size");
+    const int s = seq & 1;
+    const size_t share = (size_t)compact_bytes_;
+    const size_t rank_stride = share * max_batch_;
+    int prev = 0;
+    hip_ok(hipGetDevice(&prev), "hipGetDevice");
+    std::vector<VrFrame> frames((size_t)n);
+    // 1. every rank renders its tiles of the n poses into its COMPACT buffer of set s
+    for (int r = 0; r < n_; ++r) {
+        hip_ok(hipSetDevice(device_[r]), "hipSetDevice");
+        uint8_t* dst = (r == 0 && !rccl_self_) ? gather_[s] : compact_[s][r];
+        // set s is free again once the transfer (root: the assembly) of launch seq - 2 is done
+        if (released_used_[s][r])
+            hip_ok(hipStreamWaitEvent(hs(render_stream_[r]), he(released_[s][r]), 0),
+                   "hipStreamWaitEvent");
+        for (int i = 0; i < n; ++i) {
+            vr_default_frame(&frames[i]);
+            frames[i].rgba = dst + share * i;
+            frames[i].offscreen = 1;
+            frames[i].layout = VR_LAYOUT_COMPACT;
+            frames[i].tile_w = tile_w_;
+            frames[i].tile_h = tile_h_;
+            frames[i].rank = r;
+            frames[i].world = n_;
+            frames[i].fp_mode = fp_mode;
+        }
+        vr_ok(vr_render_batch(tree_[r], n, cams, &opt, frames.data(), render_stream_[r]),
+              "vr_render_batch");
+        hip_ok(hipEventRecord(he(rendered_[s][r]), hs(render_stream_[r])), "hipEventRecord");
+        hip_ok(hipStreamWaitEvent(hs(comm_stream_[r]), he(rendered_[s][r]), 0), "hipStreamWaitEvent");
+    }
+    // 2. the tiles travel to the root: rank r's n shares land at gather + r * rank_stride
+    if (!share_) {
+        nccl_ok(ncclGroupStart(), "ncclGroupStart");
+        for (int r = rccl_self_ ? 0 : 1; r < n_; ++r) {
+            nccl_ok(ncclSend(compact_[s][r], share * n, ncclUint8, 0, nc(comm_[r]),
+                             hs(comm_stream_[r])), "ncclSend");
+            nccl_ok(ncclRecv(gather_[s] + rank_stride * r, share * n, ncclUint8, r, nc(comm_[0]),
+                             hs(comm_stream_[0])), "ncclRecv");
+        }
+        nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+    } else {
+        hip_ok(hipSetDevice(device_[0]), "hipSetDevice");
+        for (int r = 1; r < n_; ++r) {
+            // same device: the root's communication stream copies once rank r has rendered
+            hip_ok(hipStreamWaitEvent(hs(comm_stream_[0]), he(rendered_[s][r]), 0),
+                   "hipStreamWaitEvent");
+            hip_ok(hipMemcpyAsync(gather_[s] + rank_stride * r, compact_[s][r], share * n,
+                                  hipMemcpyDeviceToDevice, hs(comm_stream_[0])), "hipMemcpyAsync");
+        }
+    }
+    // 3. the root de-interleaves the batch; 4. the buffers of set s are released
+    hip_ok(hipSetDevice(device_[0]), "hipSetDevice");
+    vr_ok(vr_assemble_tiles_batch(frames_[s], (int64_t)frame_bytes(), 0, gather_[s],
+                                  (int64_t)rank_stride, (int64_t)share, n, width_, height_, tile_w_,
+                                  tile_h_, n_, comm_stream_[0]),
+          "vr_assemble_tiles_batch");
+    for (int r = 0; r < n_; ++r) {
+        hip_ok(hipSetDevice(device_[r]), "hipSetDevice");
+        // shared device: rank r's buffer is read by the ROOT's stream
+        hipStream_t after = hs(comm_stream_[share_ ? 0 : r]);
+        hip_ok(hipEventRecord(he(released_[s][r]), after), "hipEventRecord");
+        released_used_[s][r] = true;
+    }
+    hip_ok(hipSetDevice(prev), "hipSetDevice");
+}
+
+void TileShardRenderer::sync() {
+    int prev = 0;
+    hip_ok(hipGetDevice(&prev), "hipGetDevice");
+    for (int r = 0; r < n_; ++r) {
+        hip_ok(hipSetDevice(device_[r]), "hipSetDevice");
+        hip_ok(hipStreamSynchronize(hs(render_stream_[r])), "hipStreamSynchronize");
+        hip_ok(hipStreamSynchronize(hs(comm_stream_[r])), "hipStreamSynchronize");
+    }
+    hip_ok(hipSetDevice(prev), "hipSetDevice");
+}
+
+}  // namespace internal
+}  // namespace volrend

@@ -67,6 +67,27 @@ Tuning& tuning() {
                         __LINE__);                                                          \
     } while (0)
 
+// A tree lives on ONE device; its calls run there whatever the calling thread's current device
+// is (one host thread may drive the trees of several devices), and leave the thread's device
+// as they found it.
+class DeviceGuard {
+   public:
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev_) == hipSuccess && prev_ != device) {
+            switched_ = hipSetDevice(device) == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched_) (void)hipSetDevice(prev_);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+
+   private:
+    int prev_ = 0;
+    bool switched_ = false;
+};
+
 }  // namespace
 
 constexpr unsigned kLaunchSlots = 8;
@@ -95,6 +116,9 @@ struct VrTreeOpaque {
     float* extra = nullptr;
     uint32_t* status = nullptr;
     unsigned long long* sched_stats = nullptr;  // 8 x u64, see vr_sched_stats
+    uint32_t* touch[4] = {nullptr, nullptr, nullptr, nullptr};  // distinct-line bitmaps (vr_touch_enable)
+    uint64_t array_bytes[4] = {0, 0, 0, 0};  // leaves, nodes, top, bricks
+    unsigned long long* touch_out = nullptr;
     float* probe_buf = nullptr;  // kLaunchSlots x data_dim floats: the lumisphere at opt.probe
     vr::FrameDesc* slot_frames = nullptr;  // kLaunchSlots x kMaxBatch
     uint32_t* slot_heads = nullptr;        // kLaunchSlots x kSlotWords
@@ -257,6 +281,7 @@ void fill_tree_params(vr::KParams& k, const VrTreeOpaque* t) {
     k.ndc_focal = t->desc.ndc_focal;
     k.status = t->status;
     k.sched_stats = t->sched_stats;
+    for (int i = 0; i < 4; ++i) k.touch[i] = t->touch[i];
 }
 
 }  // namespace
@@ -373,6 +398,31 @@ static int check_tree_desc(const VrTreeDesc* d, bool need_data) {
     return VR_OK;
 }
 
+// Everything of a tree that is not tree data, on the current device (= t->device): status and
+// tally words, the launch-slot ring (events, frame tables, queue heads, probe coefficients).
+static hipError_t alloc_launch_scratch(VrTreeOpaque* t) {
+    hipError_t e = hipMalloc((void**)&t->status, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(t->status, 0, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&t->sched_stats, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(t->sched_stats, 0, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&t->probe_buf,
+                      sizeof(float) * (size_t)t->desc.data_dim * kLaunchSlots);
+    for (unsigned i = 0; i < kLaunchSlots && e == hipSuccess; ++i)
+        e = hipEventCreateWithFlags(&t->slots[i].done, hipEventDisableTiming);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&t->slot_frames, sizeof(vr::FrameDesc) * vr::kMaxBatch * kLaunchSlots);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&t->slot_heads, sizeof(uint32_t) * kSlotWords * kLaunchSlots);
+    if (e == hipSuccess) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) ==
+                hipSuccess && cus > 0)
+            t->n_cus = cus;
+    }
+    return e;
+}
+
 static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out) {
     if (!d || !out) return fail(VR_ERR_INVALID_ARGUMENT, "desc/out is NULL");
     *out = nullptr;
@@ -445,24 +495,7 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     const size_t leaves_sz = n_slots * (size_t)t->leaf_stride_h * sizeof(uint16_t);
     if (e == hipSuccess) e = hipMalloc((void**)&t->nodes, child_sz);
     if (e == hipSuccess) e = hipMalloc((void**)&t->leaves, leaves_sz);
-    if (e == hipSuccess) e = hipMalloc((void**)&t->status, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(t->status, 0, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&t->sched_stats, 8 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(t->sched_stats, 0, 8 * sizeof(unsigned long long));
-    if (e == hipSuccess)
-        e = hipMalloc((void**)&t->probe_buf, sizeof(float) * (size_t)d->data_dim * kLaunchSlots);
-    for (unsigned i = 0; i < kLaunchSlots && e == hipSuccess; ++i)
-        e = hipEventCreateWithFlags(&t->slots[i].done, hipEventDisableTiming);
-    if (e == hipSuccess)
-        e = hipMalloc((void**)&t->slot_frames, sizeof(vr::FrameDesc) * vr::kMaxBatch * kLaunchSlots);
-    if (e == hipSuccess)
-        e = hipMalloc((void**)&t->slot_heads, sizeof(uint32_t) * kSlotWords * kLaunchSlots);
-    if (e == hipSuccess) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) ==
-                hipSuccess && cus > 0)
-            t->n_cus = cus;
-    }
+    if (e == hipSuccess) e = alloc_launch_scratch(t);
     int32_t* d_perm = nullptr;
     std::vector<int32_t> brick_roots;
     {
@@ -476,6 +509,8 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
         e = vr::launch_relayout(src_child, src_data, d_perm, t->nodes, t->leaves, (int64_t)n_slots,
                                 N3, d->data_dim, t->leaf_stride_h, nullptr);
     t->device_bytes = child_sz + leaves_sz + sizeof(uint32_t);
+    t->array_bytes[0] = leaves_sz;
+    t->array_bytes[1] = child_sz;
     // lookup structure: top grid + bricks (vr_kernels.hip), built from the node words
     int32_t* d_roots = nullptr;
     if (e == hipSuccess && G0 > 0) {
@@ -506,6 +541,8 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
             t->brick_levels = n_bricks ? BL : 0;
             t->n_bricks = n_bricks;
             t->device_bytes += top_sz + brick_sz;
+            t->array_bytes[2] = top_sz;
+            t->array_bytes[3] = brick_sz;
         }
     }
     if (d_roots) (void)hipFree(d_roots);
@@ -557,8 +594,59 @@ int vr_decode_quantized(const VrTreeDesc* d, const VrQuantDesc* q, uint16_t* dat
     return VR_OK;
 }
 
+int vr_tree_clone(vr_tree_t src, int device, vr_tree_t* out) {
+    if (!src || !out) return fail(VR_ERR_INVALID_ARGUMENT, "tree/out is NULL");
+    *out = nullptr;
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev)
+        return fail(VR_ERR_INVALID_ARGUMENT, "device %d outside [0,%d)", device, n_dev);
+    {   // the source may still be uploading / rendering on its own device
+        DeviceGuard g(src->device);
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    DeviceGuard guard(device);
+    VrTreeOpaque* t = new (std::nothrow) VrTreeOpaque();
+    if (!t) return fail(VR_ERR_OUT_OF_MEMORY, "host allocation failed");
+    t->device = device;
+    t->desc = src->desc;
+    t->max_depth = src->max_depth;
+    t->leaf_stride_h = src->leaf_stride_h;
+    t->top_levels = src->top_levels;
+    t->brick_levels = src->brick_levels;
+    t->n_bricks = src->n_bricks;
+    t->device_bytes = src->device_bytes;
+    for (int i = 0; i < 4; ++i) t->array_bytes[i] = src->array_bytes[i];
+    // the re-laid-out arrays travel device to device (over xGMI between two GPUs of a node):
+    // no second pass over PCIe, no second re-layout
+    void** dst[4] = {(void**)&t->leaves, (void**)&t->nodes, (void**)&t->top, (void**)&t->bricks};
+    const void* from[4] = {src->leaves, src->nodes, src->top, src->bricks};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) {
+        if (!from[i] || !t->array_bytes[i]) continue;
+        e = hipMalloc(dst[i], t->array_bytes[i]);
+        if (e == hipSuccess)
+            e = hipMemcpyPeer(*dst[i], device, from[i], src->device, t->array_bytes[i]);
+    }
+    if (e == hipSuccess && src->extra && src->desc.extra_count) {
+        const size_t esz = (size_t)src->desc.extra_count * sizeof(float);
+        e = hipMalloc((void**)&t->extra, esz);
+        if (e == hipSuccess) e = hipMemcpyPeer(t->extra, device, src->extra, src->device, esz);
+    }
+    if (e == hipSuccess) e = alloc_launch_scratch(t);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        vr_tree_free(t);
+        return fail(e == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP,
+                    "tree clone to device %d failed: %s", device, hipGetErrorString(e));
+    }
+    *out = t;
+    return VR_OK;
+}
+
 int vr_tree_free(vr_tree_t t) {
     if (!t) return VR_OK;
+    DeviceGuard guard(t->device);
     if (t->nodes) (void)hipFree(t->nodes);
     if (t->leaves) (void)hipFree(t->leaves);
     if (t->top) (void)hipFree(t->top);
@@ -566,6 +654,9 @@ int vr_tree_free(vr_tree_t t) {
     if (t->extra) (void)hipFree(t->extra);
     if (t->status) (void)hipFree(t->status);
     if (t->sched_stats) (void)hipFree(t->sched_stats);
+    for (int i = 0; i < 4; ++i)
+        if (t->touch[i]) (void)hipFree(t->touch[i]);
+    if (t->touch_out) (void)hipFree(t->touch_out);
     if (t->probe_buf) (void)hipFree(t->probe_buf);
     if (t->slot_frames) (void)hipFree(t->slot_frames);
     if (t->slot_heads) (void)hipFree(t->slot_heads);
@@ -659,8 +750,48 @@ int vr_set_tuning(const char* key, int value) {
 
 int vr_sched_stats(vr_tree_t t, uint64_t out[8], int reset) {
     if (!t || !out) return fail(VR_ERR_INVALID_ARGUMENT, "NULL argument");
+    DeviceGuard guard(t->device);
     HIP_TRY(hipMemcpy(out, t->sched_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(hipMemset(t->sched_stats, 0, 8 * sizeof(uint64_t)));
+    return VR_OK;
+}
+
+static size_t touch_words(uint64_t array_bytes) {  // one bit per 128-byte line
+    return (size_t)(((array_bytes + 127) / 128 + 31) / 32);
+}
+
+int vr_touch_enable(vr_tree_t t, int enable) {
+    if (!t) return fail(VR_ERR_INVALID_ARGUMENT, "tree is NULL");
+    DeviceGuard guard(t->device);
+    HIP_TRY(hipDeviceSynchronize());  // no launch may be using the bitmaps while they change
+    for (int i = 0; i < 4; ++i) {
+        if (t->touch[i]) {
+            HIP_TRY(hipFree(t->touch[i]));
+            t->touch[i] = nullptr;
+        }
+        const size_t words = touch_words(t->array_bytes[i]);
+        if (enable && words) {
+            HIP_TRY(hipMalloc((void**)&t->touch[i], words * sizeof(uint32_t)));
+            HIP_TRY(hipMemset(t->touch[i], 0, words * sizeof(uint32_t)));
+        }
+    }
+    if (enable && !t->touch_out) HIP_TRY(hipMalloc((void**)&t->touch_out, 4 * sizeof(unsigned long long)));
+    return VR_OK;
+}
+
+int vr_touch_count(vr_tree_t t, uint64_t out[4], int reset) {
+    if (!t || !out) return fail(VR_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!t->touch_out) return fail(VR_ERR_INVALID_ARGUMENT, "vr_touch_enable(tree, 1) first");
+    DeviceGuard guard(t->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(t->touch_out, 0, 4 * sizeof(unsigned long long)));
+    for (int i = 0; i < 4; ++i) {
+        if (!t->touch[i]) continue;
+        const size_t words = touch_words(t->array_bytes[i]);
+        HIP_TRY(vr::launch_popcount(t->touch[i], words, t->touch_out + i, nullptr));
+        if (reset) HIP_TRY(hipMemsetAsync(t->touch[i], 0, words * sizeof(uint32_t), nullptr));
+    }
+    HIP_TRY(hipMemcpy(out, t->touch_out, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return VR_OK;
 }
 
@@ -713,6 +844,7 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
         return fail(VR_ERR_INVALID_ARGUMENT, "step_size must be positive (got %g)",
                     (double)opt->step_size);
 
+    DeviceGuard device_guard(t->device);
     vr::KParams k;
     memset(&k, 0, sizeof(k));
     fill_tree_params(k, t);
@@ -836,6 +968,7 @@ int vr_reserve(vr_tree_t t, int width, int height, int n_frames) {
         return fail(VR_ERR_INVALID_ARGUMENT, "batch of %lld rays exceeds the 2^30-ray queue",
                     (long long)total);
     const size_t need = ray_buffer_bytes((uint32_t)total, basis_words_of(t));
+    DeviceGuard device_guard(t->device);
     std::lock_guard<std::mutex> guard(t->launch_mutex);
     for (unsigned i = 0; i < kLaunchSlots; ++i) {
         LaunchSlot& ls = t->slots[i];
@@ -854,6 +987,7 @@ int vr_reserve(vr_tree_t t, int width, int height, int n_frames) {
 
 int vr_tree_status(vr_tree_t t, uint32_t* status, int reset) {
     if (!t || !status) return fail(VR_ERR_INVALID_ARGUMENT, "NULL argument");
+    DeviceGuard guard(t->device);
     HIP_TRY(hipMemcpy(status, t->status, sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(hipMemset(t->status, 0, sizeof(uint32_t)));
     return VR_OK;
@@ -893,6 +1027,7 @@ int vr_assemble_tiles_batch(void* frames_rgba, int64_t frame_stride, int64_t pit
 
 int vr_probe_coeffs(vr_tree_t t, const VrRenderOptions* opt, float* out_dev, void* stream) {
     if (!t || !opt || !out_dev) return fail(VR_ERR_INVALID_ARGUMENT, "NULL argument");
+    DeviceGuard guard(t->device);
     vr::KParams k;
     memset(&k, 0, sizeof(k));
     fill_tree_params(k, t);

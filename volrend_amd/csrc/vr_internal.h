@@ -96,6 +96,9 @@ struct KParams {
     int32_t frame_minor;         // ray-id order: pixel block major, frame minor
     uint32_t* status;            // device word: bit0 = iteration cap hit
     unsigned long long* sched_stats;  // 8 x u64 scheduling tallies (instrumented flavours)
+    // distinct-line meter (instrumented flavours, vr_touch_enable): one bit per 128-byte line of
+    // leaves / nodes / top / bricks, set by every access; NULL when off
+    uint32_t* touch[4];
 };
 
 // vr_kernels.hip
@@ -117,6 +120,9 @@ hipError_t launch_relayout(const int32_t* child, const uint16_t* data, const int
 hipError_t launch_decode_quant(const uint16_t* colors, const uint16_t* map, const uint16_t* sigma,
                                const uint16_t* retained, uint16_t* data, int64_t n_slots,
                                int n_quant, int n_ret, int data_dim, hipStream_t stream);
+// number of set bits of a bitmap of n_words 32-bit words, added to *out
+hipError_t launch_popcount(const uint32_t* words, uint64_t n_words, unsigned long long* out,
+                           hipStream_t stream);
 // N == 2 lookup structure (top grid + bricks), built from the re-laid-out node words
 hipError_t launch_build_lookup(const uint32_t* nodes, const int32_t* brick_root, int n_bricks,
                                uint2* top, uint32_t* bricks, int top_levels, int brick_levels,

@@ -166,9 +166,20 @@ __device__ __forceinline__ void precalc_basis(const KParams& p, const float* dir
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr int kMaxBrickLevels = 3;   // delta field: 8 + 64 nodes below a brick root
 
+// Distinct-line meter of the instrumented flavours (SURVEY.md 8(d) "B_unique"): marks the 128-byte
+// line(s) an access of `bytes` bytes at byte offset `off` of array `which` touches.
+enum { TOUCH_LEAVES = 0, TOUCH_NODES = 1, TOUCH_TOP = 2, TOUCH_BRICKS = 3 };
+__device__ __forceinline__ void touch(const KParams& p, int which, uint64_t off, uint32_t bytes) {
+    uint32_t* bm = p.touch[which];
+    if (!bm) return;
+    const uint64_t l0 = off >> 7, l1 = (off + bytes - 1) >> 7;
+    atomicOr(&bm[l0 >> 5], 1u << (l0 & 31u));
+    if (l1 != l0) atomicOr(&bm[l1 >> 5], 1u << (l1 & 31u));
+}
+
 // octree point query, n3tree_query.hpp:13-48 -- literal float descent (any N).
 // xyz is rewritten to leaf-local coordinates; returns the leaf slot index.
-template <int FMA>
+template <int FMA, bool COUNT = false>
 __device__ __forceinline__ int64_t query_generic(const KParams& p, float* xyz, float* cube_sz,
                                                  int* levels, uint32_t* word) {
     using P = Policy<FMA>;
@@ -192,6 +203,7 @@ __device__ __forceinline__ int64_t query_generic(const KParams& p, float* xyz, f
         }
         sub_ptr = node * p.N3 + (int32_t)index;
         w = p.nodes[sub_ptr];
+        if (COUNT) touch(p, TOUCH_NODES, (uint64_t)sub_ptr * 4u, 4u);
         if (w & kLeafBit) break;
         *cube_sz *= fN;
         node = (int64_t)w;
@@ -214,6 +226,7 @@ struct Cursor {
 // chain, and the digits of several levels index a table at once.
 // Valid while the deepest leaf has d <= 24 (checked at upload).
 // Returns the leaf id; *depth = d (child words the reference reads = d), *word low 16 bits = sigma.
+template <bool COUNT = false>
 __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* depth,
                                              uint32_t* word, Cursor& cur) {
     const float hi = 1.f - 1e-6f;
@@ -227,6 +240,7 @@ __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* 
     const uint32_t cell = ((ux >> sh0) << (2u * g0)) | ((uy >> sh0) << g0) | (uz >> sh0);
     if (cell != cur.cell) {
         const uint2 e = p.top[cell];
+        if (COUNT) touch(p, TOUCH_TOP, (uint64_t)cell * 8u, 8u);
         cur.cell = cell;
         cur.e0 = e.x;
         cur.e1 = e.y;
@@ -240,6 +254,7 @@ __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* 
         const uint32_t sub = (__builtin_amdgcn_ubfe(ux, sh1, bl) << (2u * bl)) |
                              (__builtin_amdgcn_ubfe(uy, sh1, bl) << bl) |
                              __builtin_amdgcn_ubfe(uz, sh1, bl);
+        if (COUNT) touch(p, TOUCH_BRICKS, (uint64_t)((w << (3u * bl)) + sub) * 4u, 4u);
         w = p.bricks[(w << (3u * bl)) + sub];
         if (w & kLeafBit) {
             d = (int)(g0 + 1u + __builtin_amdgcn_ubfe(w, 26u, 2u));
@@ -255,6 +270,7 @@ __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* 
                 slot = (__builtin_amdgcn_ubfe(ux, sh, 1u) << 2) |
                        (__builtin_amdgcn_ubfe(uy, sh, 1u) << 1) | __builtin_amdgcn_ubfe(uz, sh, 1u);
                 w = *reinterpret_cast<const uint32_t*>(nodes_base + (node * 8u + slot) * 4u);
+                if (COUNT) touch(p, TOUCH_NODES, (uint64_t)(node * 8u + slot) * 4u, 4u);
                 if ((w & kLeafBit) || l >= 23) break;
                 node = w;
             }
@@ -783,10 +799,10 @@ typedef std::conditional<(VR_OWNER_Q > 4), uint64_t, uint32_t>::type qpos_t;
 // Register budget of the production (FAST) flavours, from their natural register use: SH16 <= 80
 // VGPRs (6 waves per SIMD -- with its 6.4 KB of LDS that is 24 waves per CU), SH9 <= 72 (7),
 // SH25 <= 128 (4: it gathers its 25 basis values up front), the small records 8.  The instrumented / lobe / generic flavours keep their
-// wider state in registers at 4 waves per SIMD.
+// wider state in registers at 4 waves per SIMD (3 for SH25: no scratch in any flavour).
 template <int BASIS, int MODE>
 constexpr int min_waves_per_eu() {
-    if (MODE != MODE_FAST) return 4;
+    if (MODE != MODE_FAST) return BASIS == BASIS_25 ? 3 : 4;  // SH25 + counters needs > 128 VGPRs
     const int want = BASIS == BASIS_25 ? 4 : BASIS == BASIS_16 ? VR_SH16_WAVES : BASIS == BASIS_9 ? 7 : 8;
     return want < VR_MIN_WAVES_PER_EU ? want : VR_MIN_WAVES_PER_EU;
 }
@@ -879,6 +895,9 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 if (o < lane && other == myleaf) first = false;
             }
             st_distinct += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(first));
+            if (lane < n)  // the record this item reads (colour coefficients only: sigma rides in the node word)
+                touch(p, TOUCH_LEAVES, (uint64_t)myleaf * (uint32_t)(p.leaf_stride_h * 2),
+                      (uint32_t)(2 * (p.data_dim - 1)));
         }
         const bool have = lane < n;
         const uint32_t jmine = (ring_head + (uint32_t)lane) & (kRing - 1);
@@ -1122,9 +1141,9 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 int levels;
                 uint32_t word;
                 if (N2) {
-                    leaf = query_n2(p, pos, &levels, &word, cur);
+                    leaf = query_n2<COUNT>(p, pos, &levels, &word, cur);
                 } else {
-                    leaf = (uint32_t)query_generic<FMA>(p, pos, &cube_sz, &levels, &word);
+                    leaf = (uint32_t)query_generic<FMA, COUNT>(p, pos, &cube_sz, &levels, &word);
                 }
                 if (COUNT) {
                     rc.samples++;
@@ -1493,6 +1512,15 @@ __global__ void decode_quant_kernel(const uint16_t* __restrict__ colors,
     }
 }
 
+__global__ void popcount_kernel(const uint32_t* words, uint64_t n_words, unsigned long long* out) {
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        acc += (unsigned long long)__builtin_popcount(words[i]);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
 // Lookup structure, part 1: top[cell] for every cell of the 2^G0-per-axis grid (layout comment
 // at the top of this file).  brick_root[] = indices of the internal nodes of level G0, ascending.
 __global__ void build_top_kernel(const uint32_t* nodes, const int32_t* brick_root, int n_bricks,
@@ -1696,6 +1724,16 @@ hipError_t launch_build_lookup(const uint32_t* nodes, const int32_t* brick_root,
         hipLaunchKernelGGL(build_bricks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                            stream, nodes, brick_root, n_bricks, bricks, brick_levels, error_flag);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_popcount(const uint32_t* words, uint64_t n_words, unsigned long long* out,
+                           hipStream_t stream) {
+    if (n_words == 0) return hipSuccess;
+    uint64_t blocks = (n_words + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(popcount_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, words, n_words,
+                       out);
     return hipGetLastError();
 }
 

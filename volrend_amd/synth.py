@@ -33,6 +33,14 @@ CONFIGS = {
                sigma=(5.0, 200.0), n_shapes=12, shape_size=(0.5, 1.0), shell_leaves=2.0),
     "C1": dict(depth=9, fmt="SH", basis_dim=16, seed=1002, width=800, height=800, focal=1111.111,
                sigma=(5.0, 200.0), n_shapes=12, shape_size=(0.5, 1.0), shell_leaves=7.5),
+    # Workload-sensitivity variants of C1 (same poses / image / options; profiles/r02_workload_*.json):
+    #   C1r: the SURVEY 8(d) recipe as written -- 12 small primitives, shell of 2 leaf widths (0.55 M nodes)
+    #   C1t: a THIN shell (2.5 leaf widths) grown to ~2 M nodes by more primitives instead of a thicker shell
+    "C1r": dict(depth=9, fmt="SH", basis_dim=16, seed=1002, width=800, height=800, focal=1111.111,
+                sigma=(5.0, 200.0), n_shapes=12, shape_size=(0.25, 0.6), shell_leaves=2.0),
+    "C1t": dict(depth=9, fmt="SH", basis_dim=16, seed=1002, width=800, height=800, focal=1111.111,
+                sigma=(5.0, 200.0), n_shapes=64, shape_size=(0.3, 0.7), shell_leaves=2.5,
+                center_range=1.3),
     "C2": dict(depth=9, fmt="SH", basis_dim=25, seed=1003, width=800, height=800, focal=1111.111,
                sigma=(1.0, 10.0), n_shapes=12, shape_size=(0.5, 1.0), shell_leaves=7.5),
     "C3": dict(depth=10, fmt="SH", basis_dim=9, seed=1004, width=1920, height=1080, focal=1166.0,
@@ -78,13 +86,13 @@ class SynthTree:
         return self.child.nbytes + self.data.nbytes
 
 
-def _random_scene(rng: np.random.Generator, n_shapes: int, size=(0.25, 0.6)):
+def _random_scene(rng: np.random.Generator, n_shapes: int, size=(0.25, 0.6), center_range=0.8):
     """Union of random spheres / axis-aligned boxes inside world radius 1.5."""
     shapes = []
     for _ in range(n_shapes):
         kind = "sphere" if rng.random() < 0.6 else "box"
         r = rng.uniform(size[0], size[1])
-        c = rng.uniform(-0.8, 0.8, size=3)
+        c = rng.uniform(-center_range, center_range, size=3)
         if kind == "sphere":
             shapes.append(("sphere", c, np.array([r, r, r])))
         else:
@@ -114,7 +122,8 @@ _SLOT_IJK = np.array([[(s >> 2) & 1, (s >> 1) & 1, s & 1] for s in range(8)], dt
 
 def make_tree(depth: int, basis_dim: int = 16, fmt: str = "SH", seed: int = 0, n_shapes: int = 12,
               sigma=(5.0, 200.0), shape_size=(0.25, 0.6), world_radius: float = 1.5,
-              shell_leaves: float = 2.0, topology_only: bool = False) -> SynthTree:
+              shell_leaves: float = 2.0, topology_only: bool = False,
+              center_range: float = 0.8) -> SynthTree:
     """Build a sparse octree refined around the surface shell of a random scene.
 
     ``depth`` = number of tree levels: the finest leaves tile 2**depth cells per
@@ -123,7 +132,7 @@ def make_tree(depth: int, basis_dim: int = 16, fmt: str = "SH", seed: int = 0, n
     """
     assert depth >= 1
     rng = np.random.default_rng(seed)
-    shapes = _random_scene(rng, n_shapes, shape_size)
+    shapes = _random_scene(rng, n_shapes, shape_size, center_range)
     invr = np.float32(0.5 / world_radius)
     leaf_w_world = (1.0 / (1 << depth)) / float(invr)
     shell = shell_leaves * leaf_w_world
@@ -239,7 +248,8 @@ def make_config_tree(name: str, **overrides) -> SynthTree:
     t = make_tree(cfg["depth"], cfg["basis_dim"], cfg["fmt"], cfg["seed"], cfg["n_shapes"],
                   cfg["sigma"], shape_size=cfg.get("shape_size", (0.25, 0.6)),
                   shell_leaves=cfg.get("shell_leaves", 2.0),
-                  topology_only=cfg.get("topology_only", False))
+                  topology_only=cfg.get("topology_only", False),
+                  center_range=cfg.get("center_range", 0.8))
     t.meta.update(config=name)
     return t
 
