@@ -461,6 +461,10 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
         if (G0 > max_depth + 1) G0 = max_depth + 1;  // deepest leaf depth
         BL = tn.brick_levels < 1 ? 1 : (tn.brick_levels > 3 ? 3 : tn.brick_levels);
         if (BL > max_depth + 1 - G0) BL = max_depth + 1 - G0;  // 0: the top grid resolves every leaf
+        // the kernel addresses brick entries with 32-bit byte offsets: keep the brick array < 4 GB
+        uint64_t n_roots = 0;
+        for (uint8_t l : level) n_roots += (l == G0);
+        while (BL > 1 && ((n_roots << (3 * BL)) * sizeof(uint32_t)) >= (1ull << 32)) --BL;
     }
 
     VrTreeOpaque* t = new (std::nothrow) VrTreeOpaque();

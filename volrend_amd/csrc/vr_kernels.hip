@@ -229,17 +229,22 @@ struct Cursor {
 template <bool COUNT = false>
 __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* depth,
                                              uint32_t* word, Cursor& cur) {
+    // clamp to [0, 1 - 1e-6] (n3tree_query.hpp:17-19) as ONE v_med3_f32 per axis: identical to
+    // max(min(x, hi), 0) for every non-NaN x (-0 -> +0 included); a NaN position (only a
+    // non-finite pose can produce one) is not defined by the reference either
     const float hi = 1.f - 1e-6f;
-    xyz[0] = vmax(vmin(xyz[0], hi), 0.f);
-    xyz[1] = vmax(vmin(xyz[1], hi), 0.f);
-    xyz[2] = vmax(vmin(xyz[2], hi), 0.f);
+    xyz[0] = __builtin_amdgcn_fmed3f(xyz[0], 0.f, hi);
+    xyz[1] = __builtin_amdgcn_fmed3f(xyz[1], 0.f, hi);
+    xyz[2] = __builtin_amdgcn_fmed3f(xyz[2], 0.f, hi);
     const uint32_t ux = (uint32_t)(xyz[0] * 16777216.f);
     const uint32_t uy = (uint32_t)(xyz[1] * 16777216.f);
     const uint32_t uz = (uint32_t)(xyz[2] * 16777216.f);
     const uint32_t g0 = (uint32_t)p.top_levels, sh0 = 24u - g0;
-    const uint32_t cell = ((ux >> sh0) << (2u * g0)) | ((uy >> sh0) << g0) | (uz >> sh0);
+    const uint32_t cell = ((((ux >> sh0) << g0) | (uy >> sh0)) << g0) | (uz >> sh0);
     if (cell != cur.cell) {
-        const uint2 e = p.top[cell];
+        // 32-bit byte offsets from a uniform base (top: <= 128 MB; bricks: < 4 GB, upload)
+        const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.top) +
+                                                        (cell << 3));
         if (COUNT) touch(p, TOUCH_TOP, (uint64_t)cell * 8u, 8u);
         cur.cell = cell;
         cur.e0 = e.x;
@@ -251,11 +256,12 @@ __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* 
         d = (int)__builtin_amdgcn_ubfe(w, 16u, 5u);
     } else {
         const uint32_t bl = (uint32_t)p.brick_levels, sh1 = sh0 - bl;
-        const uint32_t sub = (__builtin_amdgcn_ubfe(ux, sh1, bl) << (2u * bl)) |
-                             (__builtin_amdgcn_ubfe(uy, sh1, bl) << bl) |
+        const uint32_t sub = (((__builtin_amdgcn_ubfe(ux, sh1, bl) << bl) |
+                               __builtin_amdgcn_ubfe(uy, sh1, bl)) << bl) |
                              __builtin_amdgcn_ubfe(uz, sh1, bl);
-        if (COUNT) touch(p, TOUCH_BRICKS, (uint64_t)((w << (3u * bl)) + sub) * 4u, 4u);
-        w = p.bricks[(w << (3u * bl)) + sub];
+        const uint32_t entry = (w << (3u * bl)) + sub;
+        if (COUNT) touch(p, TOUCH_BRICKS, (uint64_t)entry * 4u, 4u);
+        w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.bricks) + (entry << 2));
         if (w & kLeafBit) {
             d = (int)(g0 + 1u + __builtin_amdgcn_ubfe(w, 26u, 2u));
             id = (id << 3) + __builtin_amdgcn_ubfe(w, 16u, 10u);  // (root + delta) * 8 + slot
@@ -543,7 +549,6 @@ struct Ray {
     bool alive;       // still inside `while (t < tmax)`
     bool entered;     // passed the ray/box test of rt_core.cuh:88
     bool stopped;     // ended by stop_thresh (renormalised in finish_ray)
-    int iter;
 };
 
 struct PixelRef {
@@ -598,7 +603,6 @@ __device__ __forceinline__ void setup_ray(const KParams& p, const PixelRef& r, R
     ray.out[0] = ray.out[1] = ray.out[2] = ray.out[3] = 0.f;
     ray.light = 1.f;
     ray.alive = ray.entered = ray.stopped = false;
-    ray.iter = 0;
     ray.t = 0.f;
     if (p.N <= 0) return;  // enable_draw = tree.N > 0
     float dir[3], cen[3];
@@ -696,15 +700,16 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
     using P = Policy<FMA>;
     const FrameDesc& fd = p.frames[ray.frame];
     float* out = ray.out;
+    // (COUNT <=> not the FAST flavour: render_depth launches never take FAST, launch_fp)
     if (ray.stopped) {  // rt_core.cuh:176-185, applied once every queued colour has landed
-        if (p.render_depth) out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
+        if (COUNT && p.render_depth) out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
         const float scale = 1.f / (1.f - ray.light);
         out[0] *= scale;
         out[1] *= scale;
         out[2] *= scale;
         out[3] = 1.f;
     } else if (ray.entered) {  // rt_core.cuh:189-194
-        if (p.render_depth) {
+        if (COUNT && p.render_depth) {
             out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
             out[3] = 1.f;
         } else {
@@ -790,11 +795,11 @@ struct Stage {
 };
 typedef __attribute__((address_space(1))) const void* vr_gptr_t;
 typedef __attribute__((address_space(3))) void* vr_lptr_t;
-#ifndef VR_OWNER_Q
-#define VR_OWNER_Q 4
-#endif
-constexpr int kOwnerQ = VR_OWNER_Q;  // outstanding items per ray (8-bit ring positions, packed)
-typedef std::conditional<(VR_OWNER_Q > 4), uint64_t, uint32_t>::type qpos_t;
+// Outstanding colour items per ray: four 8-bit ring positions packed in one register, the newest
+// in the top byte (a push is ONE v_alignbit_b32), the oldest at bit `qsh` = 32 - 8 * count (a pop
+// only moves qsh).  (Eight per ray, measured: -2 % on a lone 20-frame launch, nothing on a
+// 64-frame one, for a second register and a 64-bit funnel shift per push.)
+constexpr int kOwnerQ = 4;
 
 // Register budget of the production (FAST) flavours, from their natural register use: SH16 <= 80
 // VGPRs (6 waves per SIMD -- with its 6.4 KB of LDS that is 24 waves per CU), SH9 <= 72 (7),
@@ -841,7 +846,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     ray.xy = 0;
     ray.pix_off = 0;
     uint32_t ray_id = 0;  // index of the lane's ray in the ray buffer
-    ray.iter = 0;
+    uint32_t ray_start = 0;  // march round in which the lane's ray started (sample guard below)
     ray.t = 0.f;
     ray.tmax = -1.f;
     ray.light = 1.f;
@@ -855,8 +860,9 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     ray.out[0] = ray.out[1] = ray.out[2] = ray.out[3] = 0.f;
     RayCounters rc;
     Cursor cur;
-    qpos_t qpos = 0;  // up to kOwnerQ ring positions (8 bits each), oldest in the low byte
-    int qn = 0;
+    uint32_t qpos = 0;  // ring positions of this ray's outstanding items, see kOwnerQ
+    uint32_t qsh = 32;  // 32 - 8 * (number of outstanding items)
+    uint32_t rounds = 0;  // march rounds of this wave (wave-uniform)
     // wave-uniform scheduler state
     bool exhausted = false;  // the ray buffer has been handed out completely
     uint32_t chunk_next = 0, chunk_end = 0;  // this wave's private range of ray ids
@@ -988,20 +994,20 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         const uint32_t head8 = ring_head & 0xFFu;
 #pragma unroll
         for (int d = 0; d < kOwnerQ; ++d) {
-            const uint32_t idx = ((uint32_t)(qpos & 0xFFu) - head8) & 0xFFu;  // item index within the round
-            if (qn > 0 && idx < (uint32_t)n) {
+            const uint32_t pos = __builtin_amdgcn_ubfe(qpos, qsh, 8u);  // my oldest item
+            const uint32_t idx = (pos - head8) & 0xFFu;               // its index within the round
+            if (qsh < 32u && idx < (uint32_t)n) {
                 if (HAS_BASIS) {
                     ray.out[0] += res[0 * kWave + idx];
                     ray.out[1] += res[1 * kWave + idx];
                     ray.out[2] += res[2 * kWave + idx];
                 } else {
-                    const float w = it_w[(uint32_t)qpos & (kRing - 1)];
+                    const float w = it_w[pos & (kRing - 1)];
                     ray.out[0] = P::madd(res[0 * kWave + idx], w, ray.out[0]);
                     ray.out[1] = P::madd(res[1 * kWave + idx], w, ray.out[1]);
                     ray.out[2] = P::madd(res[2 * kWave + idx], w, ray.out[2]);
                 }
-                qpos >>= 8;
-                --qn;
+                qsh += 8u;
             }
         }
         ring_head += (uint32_t)n;
@@ -1011,11 +1017,11 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     for (;;) {
         // ---- retire finished rays and hand their lanes new ones, in batches ----
         TL_MARK();
-        const bool done = ray.active && !ray.alive && qn == 0;
+        const bool done = ray.active && !ray.alive && qsh == 32u;
         const unsigned long long m_done = __builtin_amdgcn_ballot_w64(done);
         const unsigned long long m_free = __builtin_amdgcn_ballot_w64(!ray.active);
         const unsigned long long m_busy =
-            __builtin_amdgcn_ballot_w64(ray.active && (ray.alive || qn > 0));
+            __builtin_amdgcn_ballot_w64(ray.active && (ray.alive || qsh < 32u));
         const int n_avail = __builtin_popcountll(m_done | m_free);
         if (COUNT) st_iter++;
         if (n_avail > 0 && (m_busy == 0ull || (!exhausted && n_avail >= p.refill_min))) {
@@ -1106,10 +1112,10 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                         ray.light = 1.f;
                         ray.active = ray.alive = ray.entered = true;
                         ray.stopped = false;
-                        ray.iter = 0;
+                        ray_start = rounds;
                         rc = RayCounters();
                         cur = Cursor();
-                        qn = 0;
+                        qsh = 32u;
                         qpos = 0;
                     }
                 }
@@ -1123,8 +1129,19 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         // ---- march: lanes with a live ray and room for another outstanding item ----
         TL_ADD(tl_refill);
         for (int m = 0; m < p.march_max; ++m) {
-            const bool go = ray.active && ray.alive && qn < kOwnerQ;
+            const bool go = ray.active && ray.alive && qsh > 0u;
             if (!wave_any(go)) break;
+            // Guard against rays that never end (not in the reference, which would spin): a ray
+            // takes at most one sample per march round, so one that has been marching for
+            // kMaxIter rounds is cut and reported -- checked once every 1024 rounds, which keeps
+            // the per-round cost at one scalar add.
+            if (((++rounds) & 1023u) == 0u) {
+                asm volatile("" ::: "memory");  // keep this a (rarely taken) scalar branch
+                if (ray.active && ray.alive && rounds - ray_start >= (uint32_t)kMaxIter) {
+                    ray.alive = false;
+                    if (p.status) atomicOr(p.status, 1u);
+                }
+            }
             if (COUNT) {
                 st_march_r++;
                 st_march_l += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(go));
@@ -1164,7 +1181,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     if (COUNT) rc.hits++;
                     const float att = vr_expf(-delta_t * ray.delta_scale * sigma);
                     weight = ray.light * (1.f - att);
-                    if (p.render_depth)
+                    if (COUNT && p.render_depth)  // (depth launches take the FULL flavour)
                         ray.out[0] = P::madd(weight, ray.t, ray.out[0]);
                     else
                         push = true;
@@ -1178,10 +1195,6 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 } else {
                     ray.t += delta_t;
                     ray.alive = ray.t < ray.tmax;
-                    if (++ray.iter >= kMaxIter) {
-                        ray.alive = false;
-                        if (p.status) atomicOr(p.status, 1u);
-                    }
                 }
             }
             // append this step's items to the ring: k-th pushing lane -> tail + k
@@ -1196,8 +1209,8 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     it_leaf[j] = leaf;
                     it_w[j] = weight;
                     it_own[j] = (uint8_t)lane;
-                    qpos |= (qpos_t)(seq & 0xFFu) << (8 * qn);
-                    ++qn;
+                    qpos = __builtin_amdgcn_alignbit(seq, qpos, 8u);  // (qpos >> 8) | seq << 24
+                    qsh -= 8u;
                 }
                 ring_tail += (uint32_t)__builtin_popcountll(m_push);
                 if (ring_tail - ring_head >= (uint32_t)ST::kShade) shade_chunk(ST::kShade);
@@ -1205,7 +1218,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         }
         // nobody can march any more (queues full / rays ended): flush what is queued
         // (at most kShade - 1 + 64 items wait here: two rounds at most)
-        while (ring_tail != ring_head && !wave_any(ray.active && ray.alive && qn < kOwnerQ)) {
+        while (ring_tail != ring_head && !wave_any(ray.active && ray.alive && qsh > 0u)) {
             const uint32_t waiting = ring_tail - ring_head;
             shade_chunk(waiting < (uint32_t)ST::kShade ? (int)waiting : ST::kShade);
         }
@@ -1628,7 +1641,7 @@ hipError_t launch_fp(const KParams& p, int64_t want, int n_cus, int waves_overri
     const bool n2 = (p.N == 2) && p.top_levels > 0;  // built at upload when the tree qualifies
     const bool lobes = p.format == VR_FORMAT_SG || p.format == VR_FORMAT_ASG;
     if (!n2) return launch_basis<FMA, MODE_GENERIC>(p, want, n_cus, waves_override, s);
-    if (lobes || p.instrumented)
+    if (lobes || p.instrumented || p.render_depth)  // the depth visualisation lives outside FAST
         return launch_basis<FMA, MODE_FULL>(p, want, n_cus, waves_override, s);
     return launch_basis<FMA, MODE_FAST>(p, want, n_cus, waves_override, s);
 }
@@ -1648,7 +1661,8 @@ hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_ove
     {   // ray generation: kGenWaves wave blocks (8x8 pixels each) per workgroup
         const dim3 ggrid((unsigned)((total_blocks + kGenWaves - 1) / kGenWaves));
         const dim3 gblock(kWave * kGenWaves);
-        const bool full = p.instrumented || p.format == VR_FORMAT_SG || p.format == VR_FORMAT_ASG;
+        const bool full = p.instrumented || p.render_depth || p.format == VR_FORMAT_SG ||
+                          p.format == VR_FORMAT_ASG;
         if (fp_mode == VR_FP_FMA) {
             if (full) hipLaunchKernelGGL((raygen_kernel<1, true>), ggrid, gblock, 0, stream, p);
             else hipLaunchKernelGGL((raygen_kernel<1, false>), ggrid, gblock, 0, stream, p);
