@@ -323,12 +323,12 @@ def main():
         return pipe.run(n_steps, B, render, assemble, first)
 
     # ---- warm-up (untimed) ---------------------------------------------------
-    # The library grows one ray buffer per launch slot (4 slots, rotated) on first use -- a
-    # blocking multi-GB hipMalloc.  Make sure every slot has seen a full-size launch before
-    # the clock starts: at least 4 warm-up launches, whatever W is.
+    # W untimed steps; at least one full-size launch per launch stream so that every launch slot
+    # the timed region will use owns its ray buffer (the library grows it on first use -- a
+    # blocking multi-GB hipMalloc that must not land inside the timed region).
     n_warm = run(args.warmup, 0)
-    if n_warm < 4:
-        run((4 - n_warm) * B, args.warmup)
+    if args.warmup < n_streams * B:
+        run(n_streams * B, args.warmup)
     torch.cuda.synchronize()
 
     # ---- algorithmic bytes: instrumented flavour, outside the timed region -----

@@ -34,12 +34,14 @@
  *
  * Launches in flight.  Unlike the reference's launch_renderer, a launch here
  * carries per-launch scratch in device memory (frame table, ray queue, ray
- * buffer, probe coefficients).  The library keeps a ring of 8 such launch
- * slots per tree; each slot remembers the last launch that used it with an
- * event, and a later launch that lands on the slot makes ITS stream wait for
- * that event (a device-side wait -- the host never blocks).  So any number of
- * launches on any number of streams and host threads is safe; more than 8
- * un-finished launches of one tree simply serialise.  The one host-blocking
+ * buffer, probe coefficients).  The library keeps 8 such launch slots per
+ * tree; each slot remembers the last launch that used it with an event, and a
+ * later launch that lands on the slot makes ITS stream wait for that event (a
+ * device-side wait -- the host never blocks).  A launch takes the slot its own
+ * stream used last, else one whose launch has finished, else queues up behind
+ * the oldest.  So any number of launches on any number of streams and host
+ * threads is safe; more than 8 un-finished launches on more than 8 streams of
+ * one tree simply serialise.  The one host-blocking
  * step is the (re)allocation of a slot's ray buffer the first time a slot sees
  * a batch larger than any before -- call vr_reserve() once to take that out of
  * the render loop.
@@ -229,9 +231,10 @@ int vr_render(vr_tree_t tree, const VrCamera* cam, const VrRenderOptions* opt,
 #define VR_MAX_BATCH 512
 int vr_render_batch(vr_tree_t tree, int n_frames, const VrCamera* cams,
                     const VrRenderOptions* opt, const VrFrame* frames, void* stream);
-/* Pre-allocates the ray buffers of every launch slot for batches of up to n_frames whole
- * width x height frames, so that no later vr_render / vr_render_batch of that size (or
- * smaller, or tile-sharded) allocates or blocks.  Optional; synchronous. */
+/* Pre-allocates the ray buffers of two launch slots for batches of up to n_frames whole
+ * width x height frames (128-228 bytes per ray): a render loop on one stream lives in one slot,
+ * two alternating streams in two, so no later vr_render / vr_render_batch of that size (or
+ * smaller, or tile-sharded) on them allocates or blocks.  Optional; synchronous. */
 int vr_reserve(vr_tree_t tree, int width, int height, int n_frames);
 /* Sticky device status word of the tree's launches: bit 0 = some ray hit the 2^22-sample
  * guard (the reference would still be looping).  Synchronous; reset != 0 clears it.

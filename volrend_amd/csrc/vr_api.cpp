@@ -94,13 +94,17 @@ constexpr unsigned kLaunchSlots = 8;
 constexpr unsigned kSlotWords = 160;  // [0] ray count, [16 + 16*x] queue head x (x < 8)
 
 // Per-launch scratch that a kernel reads while it runs: frame table, queue heads, ray count,
-// ray buffer, probe coefficients.  A launch takes the next slot of a ring; `done` is recorded
-// on the launch's stream behind its last kernel and the next user of the slot makes ITS stream
-// wait for it (device-side wait, the host never blocks), so any number of launches on any
-// number of streams may be in flight -- beyond kLaunchSlots they simply serialise.
+// ray buffer, probe coefficients.  `done` is recorded on the launch's stream behind its last
+// kernel and the next user of the slot makes ITS stream wait for it (device-side wait, the host
+// never blocks), so any number of launches on any number of streams may be in flight -- beyond
+// kLaunchSlots they simply serialise.  A launch prefers the slot its own stream used last (the
+// stream orders the two launches anyway), then a slot whose last launch has finished, and only
+// then the next slot of the ring: a render loop on one stream lives in ONE slot and one ray
+// buffer however far the host runs ahead, two alternating streams in two.
 struct LaunchSlot {
     hipEvent_t done = nullptr;
     bool used = false;          // `done` has been recorded at least once
+    hipStream_t last_stream = nullptr;  // the stream of that launch
     uint32_t* rays = nullptr;   // ray buffer, grown on demand (or up front by vr_reserve)
     size_t ray_bytes = 0;
 };
@@ -253,7 +257,7 @@ int basis_words_of(const VrTreeOpaque* t) {
 }
 
 size_t ray_buffer_bytes(uint32_t total_rays, int basis_words) {
-    return (size_t)total_rays * (15 + (size_t)basis_words) * sizeof(uint32_t);
+    return (size_t)total_rays * (16 + (size_t)basis_words) * sizeof(uint32_t);  // kRayWords + basis
 }
 
 void fill_tree_params(vr::KParams& k, const VrTreeOpaque* t) {
@@ -826,7 +830,7 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     if (!(cam->fx != 0.f) || !(cam->fy != 0.f))
         return fail(VR_ERR_INVALID_ARGUMENT, "focal length must be non-zero");
 
-    bool instrumented = false;
+    bool instrumented = false, any_accum = false;
     for (int i = 0; i < n_frames; ++i) {
         const VrFrame& fi = frames[i];
         const VrCamera& ci = cams[i];
@@ -840,6 +844,7 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
             fi.world != f->world || fi.fp_mode != f->fp_mode)
             return fail(VR_ERR_INVALID_ARGUMENT, "frame %d: layout/shard/fp_mode differ within the batch", i);
         instrumented = instrumented || fi.counters != nullptr;
+        any_accum = any_accum || fi.accum != nullptr;
     }
 
     // the reference spins forever on step_size <= 0 (rt_core.cuh:108-175: t never advances past
@@ -899,6 +904,7 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.offscreen = f->offscreen != 0;
     k.layout = f->layout;
     k.instrumented = instrumented ? 1 : 0;
+    k.any_accum = any_accum ? 1 : 0;
     const Tuning& tn = tuning();
     k.march_max = tn.march_max;
     k.refill_min = tn.refill_min;
@@ -907,7 +913,24 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     // launch slot: per-launch scratch in device memory (ring, see LaunchSlot)
     hipStream_t hs = static_cast<hipStream_t>(stream);
     std::lock_guard<std::mutex> guard(t->launch_mutex);
-    const unsigned slot = t->launch_seq++ % kLaunchSlots;
+    const size_t need = ray_buffer_bytes(k.total_rays, basis_words_of(t));
+    unsigned slot = kLaunchSlots;
+    for (int want_fit = 1; want_fit >= 0 && slot == kLaunchSlots; --want_fit) {
+        for (int pass = 0; pass < 2 && slot == kLaunchSlots; ++pass)
+            for (unsigned i = 0; i < kLaunchSlots; ++i) {
+                const LaunchSlot& c = t->slots[i];
+                if (want_fit && c.ray_bytes < need) continue;
+                const bool ok = pass == 0 ? (c.used && c.last_stream == hs)
+                                          : (!c.used || hipEventQuery(c.done) == hipSuccess);
+                if (ok) {
+                    slot = i;
+                    break;
+                }
+            }
+    }
+    (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is an answer, not an error
+    if (slot == kLaunchSlots) slot = t->launch_seq % kLaunchSlots;  // all busy elsewhere: queue up
+    t->launch_seq++;
     LaunchSlot& ls = t->slots[slot];
     k.frames = t->slot_frames + (size_t)slot * vr::kMaxBatch;
     k.queue_head = t->slot_heads + kSlotWords * slot + 16;
@@ -916,7 +939,6 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.chunk_max = tn.chunk_max;
     k.ray_count = k.ray_count_rw;
     k.basis_words = basis_words_of(t);
-    const size_t need = ray_buffer_bytes(k.total_rays, k.basis_words);
     if (ls.ray_bytes < need) {
         // First use of the slot, or a larger batch than any before: (re)allocate.  This is the
         // one place where an enqueue-only call may block -- on THIS slot's previous launch
@@ -957,6 +979,7 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     HIP_TRY(vr::launch_render(k, f->fp_mode, t->n_cus, tn.waves_per_cu, hs));
     HIP_TRY(hipEventRecord(ls.done, hs));
     ls.used = true;
+    ls.last_stream = hs;
     return VR_OK;
 }
 
@@ -974,7 +997,8 @@ int vr_reserve(vr_tree_t t, int width, int height, int n_frames) {
     const size_t need = ray_buffer_bytes((uint32_t)total, basis_words_of(t));
     DeviceGuard device_guard(t->device);
     std::lock_guard<std::mutex> guard(t->launch_mutex);
-    for (unsigned i = 0; i < kLaunchSlots; ++i) {
+    // two slots: what a render loop on one stream (one slot) or on two alternating streams needs
+    for (unsigned i = 0; i < 2; ++i) {
         LaunchSlot& ls = t->slots[i];
         if (ls.ray_bytes >= need) continue;
         if (ls.rays) {

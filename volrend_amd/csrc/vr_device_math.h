@@ -125,6 +125,31 @@ static __device__ __forceinline__ float vr_expf(float x) {
     return __builtin_amdgcn_ldexpf(y, (int)kf);
 }
 
+// Two independent vr_expf in one instruction stream: the multiplies / fmas / adds are packed
+// (v_pk_mul_f32, v_pk_fma_f32, v_pk_add_f32: two binary32 operations per lane and issue slot,
+// each rounded exactly like its scalar form), clamp / rint / ldexp stay per component.  Every
+// component goes through the operation sequence of vr_expf above -- same bits.
+typedef float float2v __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ float2v splat2(float v) { return (float2v){v, v}; }
+static __device__ __forceinline__ float2v vr_expf2(float2v x) {
+    x.x = __builtin_amdgcn_fmed3f(x.x, -104.0f, 89.0f);
+    x.y = __builtin_amdgcn_fmed3f(x.y, -104.0f, 89.0f);
+    const float2v t = x * splat2(1.44269502162933349609375f);
+    const float2v kf = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
+    float2v r = __builtin_elementwise_fma(kf, splat2(-0.693145751953125f), x);
+    r = __builtin_elementwise_fma(kf, splat2(-1.428606765330187045037746429443359375e-06f), r);
+    float2v p = splat2(1.9875691500e-4f);
+    p = __builtin_elementwise_fma(p, r, splat2(1.3981999507e-3f));
+    p = __builtin_elementwise_fma(p, r, splat2(8.3334519073e-3f));
+    p = __builtin_elementwise_fma(p, r, splat2(4.1665795894e-2f));
+    p = __builtin_elementwise_fma(p, r, splat2(1.6666665459e-1f));
+    p = __builtin_elementwise_fma(p, r, splat2(5.0000001201e-1f));
+    const float2v r2 = r * r;
+    float2v y = __builtin_elementwise_fma(p, r2, r);
+    y = y + splat2(1.0f);
+    return (float2v){__builtin_amdgcn_ldexpf(y.x, (int)kf.x), __builtin_amdgcn_ldexpf(y.y, (int)kf.y)};
+}
+
 template <int FMA>
 static __device__ __forceinline__ float norm3(const float* d) {
     using P = Policy<FMA>;

@@ -93,6 +93,7 @@ struct KParams {
     int32_t march_max;           // march steps per lane between two shade checks
     int32_t shade_min;           // shade once this many lanes have queued colour work
     int32_t instrumented;        // any frame carries counters -> FULL flavour
+    int32_t any_accum;           // some frame of the launch asks for its fp32 accumulators
     int32_t frame_minor;         // ray-id order: pixel block major, frame minor
     uint32_t* status;            // device word: bit0 = iteration cap hit
     unsigned long long* sched_stats;  // 8 x u64 scheduling tallies (instrumented flavours)

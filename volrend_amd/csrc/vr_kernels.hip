@@ -39,6 +39,13 @@ constexpr int kWave = 64;
 #ifndef VR_SH16_WAVES
 #define VR_SH16_WAVES 5
 #endif
+#ifndef VR_PAIRED_CHANNELS
+#define VR_PAIRED_CHANNELS 0  // 1: strict model, channels 0/1 accumulate in a register pair (v_pk_add_f32):
+                               // -15 VALU per SH16 round but +5 live registers = scratch at 96 VGPRs
+#endif
+#ifndef VR_PACKED_EXP
+#define VR_PACKED_EXP 1       // the sigmoids of channels 0/1 share packed mul / fma / add instructions
+#endif
 constexpr int kMaxIter = 1 << 22;  // guard against step_size <= 0 (upstream would spin forever)
 
 enum { BASIS_RGBA = -1, BASIS_1 = 1, BASIS_4 = 4, BASIS_9 = 9, BASIS_16 = 16, BASIS_25 = 25 };
@@ -477,6 +484,48 @@ __device__ __forceinline__ void add_group(const char* row, GET&& get, float* acc
     }
 }
 
+// STRICT model, channels 0 and 1 side by side: their group sums are the same chain of roundings
+// on different coefficients, so the two running sums live in one register pair and every
+// "+ product" of the pair is ONE v_pk_add_f32 (the products stay v_fma_mix_f32, one per
+// coefficient).  5 instead of 6 VALU instructions per basis function; bit-identical to
+// add_group<0, ...> (each component of a packed add rounds like the scalar add).
+template <int BASIS, int LO, int HI, typename GET>
+__device__ __forceinline__ void add_group_paired(const char* row, GET&& get, float2v& a01, float& a2) {
+    float b[VR_MAX_BASIS];
+#pragma unroll
+    for (int i = LO; i <= HI; ++i) b[i] = get(i);
+    GroupWin<BASIS, 0, LO, HI> w0;
+    GroupWin<BASIS, 1, LO, HI> w1;
+    w0.load(row);
+    w1.load(row);
+    // g = b[LO]*v[LO] + b[LO+1]*v[LO+1], then + b[I]*v[I] for I = LO+2 .. HI  (DotGroup::run)
+    float2v g = (float2v){coef_mul<0 * BASIS + LO>(b[LO], w0), coef_mul<1 * BASIS + LO>(b[LO], w1)} +
+                (float2v){coef_mul<0 * BASIS + LO + 1>(b[LO + 1], w0),
+                          coef_mul<1 * BASIS + LO + 1>(b[LO + 1], w1)};
+    __builtin_amdgcn_sched_barrier(0);
+    auto step = [&](auto I) {
+        constexpr int i = decltype(I)::value;
+        g = (float2v){coef_mul<0 * BASIS + i>(b[i], w0), coef_mul<1 * BASIS + i>(b[i], w1)} + g;
+        // (the products are independent of the chain: unfenced, the scheduler computes them all
+        // up front and the register allocator pays for it with scratch)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (LO + 2 <= HI) step(std::integral_constant<int, LO + 2>{});
+    if constexpr (LO + 3 <= HI) step(std::integral_constant<int, LO + 3>{});
+    if constexpr (LO + 4 <= HI) step(std::integral_constant<int, LO + 4>{});
+    if constexpr (LO + 5 <= HI) step(std::integral_constant<int, LO + 5>{});
+    if constexpr (LO + 6 <= HI) step(std::integral_constant<int, LO + 6>{});
+    if constexpr (LO + 7 <= HI) step(std::integral_constant<int, LO + 7>{});
+    if constexpr (LO + 8 <= HI) step(std::integral_constant<int, LO + 8>{});
+    static_assert(HI - LO <= 8, "groups of at most nine basis functions");
+    a01 = a01 + g;
+    {
+        GroupWin<BASIS, 2, LO, HI> w2;
+        w2.load(row);
+        a2 += DotGroup<0, 2 * BASIS, LO, HI>::run(b, w2);
+    }
+}
+
 template <int FMA, int BASIS, typename GET>
 __device__ __forceinline__ void channel_sums(const char* row, GET&& get, float* acc) {
     static_assert(BASIS > 1, "SH / SG / ASG sizes only");
@@ -492,10 +541,20 @@ __device__ __forceinline__ void channel_sums(const char* row, GET&& get, float* 
         acc[1] = coef_mul<1 * BASIS>(b0, w1);
         acc[2] = coef_mul<2 * BASIS>(b0, w2);
     }
-    if constexpr (BASIS == 25) add_group<FMA, BASIS, 16, 24>(row, get, acc);
-    if constexpr (BASIS >= 16) add_group<FMA, BASIS, 9, 15>(row, get, acc);
-    if constexpr (BASIS >= 9) add_group<FMA, BASIS, 4, 8>(row, get, acc);
-    if constexpr (BASIS >= 4) add_group<FMA, BASIS, 1, 3>(row, get, acc);
+    if constexpr (FMA == 0 && VR_PAIRED_CHANNELS) {
+        float2v a01 = {acc[0], acc[1]};
+        if constexpr (BASIS == 25) add_group_paired<BASIS, 16, 24>(row, get, a01, acc[2]);
+        if constexpr (BASIS >= 16) add_group_paired<BASIS, 9, 15>(row, get, a01, acc[2]);
+        if constexpr (BASIS >= 9) add_group_paired<BASIS, 4, 8>(row, get, a01, acc[2]);
+        if constexpr (BASIS >= 4) add_group_paired<BASIS, 1, 3>(row, get, a01, acc[2]);
+        acc[0] = a01.x;
+        acc[1] = a01.y;
+    } else {
+        if constexpr (BASIS == 25) add_group<FMA, BASIS, 16, 24>(row, get, acc);
+        if constexpr (BASIS >= 16) add_group<FMA, BASIS, 9, 15>(row, get, acc);
+        if constexpr (BASIS >= 9) add_group<FMA, BASIS, 4, 8>(row, get, acc);
+        if constexpr (BASIS >= 4) add_group<FMA, BASIS, 1, 3>(row, get, acc);
+    }
 }
 
 __device__ __forceinline__ uint32_t quant8(float v) {
@@ -542,9 +601,6 @@ struct Ray {
     float t, tmax, delta_scale;
     float light;
     float out[4];
-    uint32_t xy;       // x | y << 16
-    uint32_t pix_off;  // byte offset of the pixel inside its frame's rgba buffer
-    int frame;
     bool active;      // lane holds an unfinished ray
     bool alive;       // still inside `while (t < tmax)`
     bool entered;     // passed the ray/box test of rt_core.cuh:88
@@ -695,10 +751,12 @@ __device__ __forceinline__ void setup_ray(const KParams& p, const PixelRef& r, R
 // End of trace_ray + the compositing tail of render_kernel (rt_core.cuh:176-194,
 // volrend.cu:152-172): early-stop renormalisation / final alpha, optional debug
 // outputs, composite, quantise, store.
+// px = the pixel's RGBA8 in its frame buffer; xy (x | y << 16) and frame are only read by the
+// optional outputs (accumulators / counters).
 template <int FMA, bool COUNT>
-__device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const RayCounters& rc) {
+__device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const RayCounters& rc,
+                                           uint8_t* px, uint32_t xy, int frame) {
     using P = Policy<FMA>;
-    const FrameDesc& fd = p.frames[ray.frame];
     float* out = ray.out;
     // (COUNT <=> not the FAST flavour: render_depth launches never take FAST, launch_fp)
     if (ray.stopped) {  // rt_core.cuh:176-185, applied once every queued colour has landed
@@ -716,7 +774,8 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
             out[3] = 1.f - ray.light;
         }
     }
-    if (COUNT && fd.counters) {
+    if (COUNT && p.frames[frame].counters) {
+        const FrameDesc& fd = p.frames[frame];
         // VrCounters: rays, rays_hit_box, samples, child_reads, hit_samples, alg_bytes,
         // early_stops.  alg_bytes per SURVEY.md 8(d):
         //   sum over samples (4*L + 2 + hit*2*(data_dim-1)) + 4 per pixel
@@ -731,11 +790,13 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
         atomicAdd(&fd.counters[5], bytes);
         atomicAdd(&fd.counters[6], (unsigned long long)rc.early);
     }
-    const int32_t x = (int32_t)(ray.xy & 0xFFFFu), y = (int32_t)(ray.xy >> 16);
-    const int64_t pix = (int64_t)y * p.width + x;
-    if (fd.accum)
-        reinterpret_cast<float4*>(fd.accum)[pix] = make_float4(out[0], out[1], out[2], out[3]);
-    uint8_t* px = fd.rgba + ray.pix_off;
+    if (p.any_accum) {  // launch-uniform: the frame table is only consulted when some frame asks
+        float* accum = p.frames[frame].accum;
+        if (accum) {
+            const int64_t pix = (int64_t)(xy >> 16) * p.width + (int64_t)(xy & 0xFFFFu);
+            reinterpret_cast<float4*>(accum)[pix] = make_float4(out[0], out[1], out[2], out[3]);
+        }
+    }
     // composite, volrend.cu:152-172
     const float nalpha = 1.f - out[3];
     if (p.offscreen) {
@@ -753,10 +814,11 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
 }
 
 // ---------------------------------------------------------------------------
-// Ray buffer (global memory, written by raygen_kernel, structure of arrays: field
-// f of ray r at word f*capacity + r):
-//   0-2 cen, 3-5 dir, 6-8 invdir, 9 t, 10 tmax, 11 delta_scale, 12 xy,
-//   13 pix_off, 14 frame, 15.. basis_fn[0..nb)
+// Ray buffer (global memory, written by raygen_kernel; blocked structure of arrays, see
+// ray_slot), the words of a ray:
+//   0-2 cen, 3-5 dir, 6-8 invdir, 9 t, 10 tmax, 11 delta_scale, 12 xy, 13-14 the 64-bit
+//   address of the pixel's RGBA8 (so that retiring a ray needs no frame-table lookup),
+//   15 frame, 16.. basis_fn[0..nb)
 // Wave-private LDS of the march kernel (one wave per workgroup):
 //   ring  : colour work items (leaf, weight, owner lane) in sample order
 //   stage : the SH records of one shade round, DMA'd straight from HBM (global_load_lds)
@@ -767,7 +829,18 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
 // instead frees 16 VGPRs but costs 37 % frame time: 16 more lines per shade round that the
 // record stream keeps evicting from L2 -- measured, profiles/r02_experiments.md.)
 // ---------------------------------------------------------------------------
-constexpr int kRayWords = 15;
+constexpr int kRayWords = 16;
+// Blocked structure of arrays: the rays are stored in blocks of 64, word k of the 64 rays of a
+// block contiguous (256 bytes), the words of a block back to back.  So word k of ray r lives at
+//   buf + ((r >> 6) * words_per_ray + k) * 64 + (r & 63)
+// -- lanes that hold consecutive rays read / write consecutive dwords, and all the words of one
+// ray hang off ONE per-lane address with compile-time offsets (k * 256 bytes: the immediate
+// field of the load), so neither address arithmetic nor a base register per field is spent.
+template <typename T>
+__device__ __forceinline__ T* ray_slot(T* buf, int words_per_ray, uint32_t r) {
+    return buf + ((size_t)(r >> 6) * (uint32_t)words_per_ray * 64u + (r & 63u));
+}
+__device__ __forceinline__ uint32_t ray_word(const uint32_t* slot, int k) { return slot[k * 64]; }
 constexpr int kRing = 128;   // capacity; at most 127 items are ever outstanding
 constexpr int kQueueStride = 16;  // words between queue heads (one 64-byte line each)
 
@@ -842,11 +915,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     Ray ray;
     ray.active = false;
     ray.alive = ray.entered = ray.stopped = false;
-    ray.frame = 0;
-    ray.xy = 0;
-    ray.pix_off = 0;
     uint32_t ray_id = 0;  // index of the lane's ray in the ray buffer
-    uint32_t ray_start = 0;  // march round in which the lane's ray started (sample guard below)
     ray.t = 0.f;
     ray.tmax = -1.f;
     ray.light = 1.f;
@@ -862,13 +931,13 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     Cursor cur;
     uint32_t qpos = 0;  // ring positions of this ray's outstanding items, see kOwnerQ
     uint32_t qsh = 32;  // 32 - 8 * (number of outstanding items)
-    uint32_t rounds = 0;  // march rounds of this wave (wave-uniform)
+    uint32_t rounds = 0, progress_round = 0;  // march rounds of this wave; the last one before a retire
     // wave-uniform scheduler state
     bool exhausted = false;  // the ray buffer has been handed out completely
     uint32_t chunk_next = 0, chunk_end = 0;  // this wave's private range of ray ids
     uint32_t ring_head = 0, ring_tail = 0;  // items [head, tail) are waiting for a shader lane
     const uint32_t total = *p.ray_count;  // rays that entered the volume (raygen_kernel)
-    const uint32_t cap = p.total_rays;     // field stride of the ray buffer
+    const int wpr = kRayWords + p.basis_words;  // words per ray in the ray buffer
     // scheduling statistics (instrumented flavours only): rounds and busy lanes per phase
     uint32_t st_march_r = 0, st_march_l = 0, st_shade_r = 0, st_shade_l = 0, st_distinct = 0,
              st_fin_r = 0, st_fin_l = 0, st_iter = 0;
@@ -959,8 +1028,15 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                         const char* row = stage + (lane % ST::kPass) * ST::kRow;
                         float acc[3];
                         channel_sums<FMA, BASIS>(row, basis_get, acc);
-                        r0 = weight / (1.f + vr_expf(-acc[0]));
-                        r1 = weight / (1.f + vr_expf(-acc[1]));
+                        // rt_core.cuh:161: weight / (1 + expf(-tmp)) per channel
+                        if constexpr (VR_PACKED_EXP) {
+                            const float2v e01 = vr_expf2((float2v){-acc[0], -acc[1]}) + splat2(1.f);
+                            r0 = weight / e01.x;
+                            r1 = weight / e01.y;
+                        } else {
+                            r0 = weight / (1.f + vr_expf(-acc[0]));
+                            r1 = weight / (1.f + vr_expf(-acc[1]));
+                        }
                         r2 = weight / (1.f + vr_expf(-acc[2]));
                     }
                     if (ST::kPasses > 1) __syncthreads();  // rows are free for the next pass
@@ -1029,14 +1105,23 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 st_fin_r++;
                 st_fin_l += (uint32_t)__builtin_popcountll(m_done);
             }
+            // The whole round costs ONE memory round trip: the pixel address of every finished
+            // ray is requested here, the new rays right behind it, and the finished rays are
+            // composited and stored once everything has landed (their colour state does not
+            // overlap the registers the new rays load into).
+            uint32_t px_lo = 0, px_hi = 0, fin_xy = 0, fin_frame = 0;
             if (done) {
-                const uint32_t* rb = p.ray_buf + ray_id;  // the pixel this ray belongs to
-                ray.xy = rb[(size_t)12 * cap];
-                ray.pix_off = rb[(size_t)13 * cap];
-                ray.frame = (int)rb[(size_t)14 * cap];
-                finish_ray<FMA, COUNT>(p, ray, rc);
-                ray.active = false;
+                const uint32_t* rs = ray_slot(p.ray_buf, wpr, ray_id);
+                px_lo = ray_word(rs, 13);
+                px_hi = ray_word(rs, 14);
+                if (COUNT || p.any_accum) {
+                    fin_xy = ray_word(rs, 12);
+                    fin_frame = ray_word(rs, 15);
+                }
             }
+            const bool vacant = done || !ray.active;
+            bool take = false;
+            progress_round = rounds;
             // Idle lanes take consecutive rays from the buffer.  The wave owns a private
             // chunk [chunk_next, chunk_end) of ray ids and only goes to the global queue
             // head (ONE returning atomic -- a single word sustains ~90 of them per
@@ -1090,35 +1175,40 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 const uint32_t c_end = chunk_end;
                 const uint32_t left = chunk_end - chunk_next;
                 chunk_next += (uint32_t)n_avail < left ? (uint32_t)n_avail : left;
-                if (!ray.active) {
-                    if (r < c_end) {
-                        const uint32_t* rb = p.ray_buf + r;
+                if (vacant && r < c_end) {
+                    take = true;
+                    const uint32_t* rs = ray_slot(p.ray_buf, wpr, r);
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            ray.cen[i] = u2f(rb[(size_t)(0 + i) * cap]);
-                            ray.dir[i] = u2f(rb[(size_t)(3 + i) * cap]);
-                            ray.invdir[i] = u2f(rb[(size_t)(6 + i) * cap]);
-                        }
-                        ray.t = u2f(rb[(size_t)9 * cap]);
-                        ray.tmax = u2f(rb[(size_t)10 * cap]);
-                        ray.delta_scale = u2f(rb[(size_t)11 * cap]);
-                        ray_id = r;
-                        if (HAS_BASIS) {
+                    for (int i = 0; i < 3; ++i) {
+                        ray.cen[i] = u2f(ray_word(rs, 0 + i));
+                        ray.dir[i] = u2f(ray_word(rs, 3 + i));
+                        ray.invdir[i] = u2f(ray_word(rs, 6 + i));
+                    }
+                    ray.t = u2f(ray_word(rs, 9));
+                    ray.tmax = u2f(ray_word(rs, 10));
+                    ray.delta_scale = u2f(ray_word(rs, 11));
+                    ray_id = r;
+                    if (HAS_BASIS) {
 #pragma unroll
-                            for (int i = 0; i < NB; ++i)
-                                mybasis[i] = u2f(rb[(size_t)(kRayWords + i) * cap]);
-                        }
-                        ray.out[0] = ray.out[1] = ray.out[2] = ray.out[3] = 0.f;
-                        ray.light = 1.f;
-                        ray.active = ray.alive = ray.entered = true;
-                        ray.stopped = false;
-                        ray_start = rounds;
-                        rc = RayCounters();
-                        cur = Cursor();
-                        qsh = 32u;
-                        qpos = 0;
+                        for (int i = 0; i < NB; ++i)
+                            mybasis[i] = u2f(ray_word(rs, kRayWords + i));
                     }
                 }
+            }
+            if (done)
+                finish_ray<FMA, COUNT>(
+                    p, ray, rc,
+                    reinterpret_cast<uint8_t*>(((uint64_t)px_hi << 32) | (uint64_t)px_lo), fin_xy,
+                    (int)fin_frame);
+            if (vacant) {
+                ray.active = ray.alive = ray.entered = take;
+                ray.out[0] = ray.out[1] = ray.out[2] = ray.out[3] = 0.f;
+                ray.light = 1.f;
+                ray.stopped = false;
+                rc = RayCounters();
+                cur = Cursor();
+                qsh = 32u;
+                qpos = 0;
             }
         }
         if (!wave_any(ray.active)) {
@@ -1131,16 +1221,17 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         for (int m = 0; m < p.march_max; ++m) {
             const bool go = ray.active && ray.alive && qsh > 0u;
             if (!wave_any(go)) break;
-            // Guard against rays that never end (not in the reference, which would spin): a ray
-            // takes at most one sample per march round, so one that has been marching for
-            // kMaxIter rounds is cut and reported -- checked once every 1024 rounds, which keeps
-            // the per-round cost at one scalar add.
-            if (((++rounds) & 1023u) == 0u) {
+            // Guard against rays that never end (not in the reference, which would spin): when
+            // the wave has marched kMaxIter rounds without retiring a single ray, whatever is
+            // still marching is cut and reported.  Wave-uniform state only: one scalar add per
+            // round, checked every 1024 rounds.
+            if (((++rounds) & 1023u) == 0u && rounds - progress_round >= (uint32_t)kMaxIter) {
                 asm volatile("" ::: "memory");  // keep this a (rarely taken) scalar branch
-                if (ray.active && ray.alive && rounds - ray_start >= (uint32_t)kMaxIter) {
+                if (ray.active && ray.alive) {
                     ray.alive = false;
                     if (p.status) atomicOr(p.status, 1u);
                 }
+                progress_round = rounds;
             }
             if (COUNT) {
                 st_march_r++;
@@ -1268,20 +1359,22 @@ __global__ __launch_bounds__(kWave* kGenWaves) void raygen_kernel(const KParams 
         (uint32_t)(((int64_t)blockIdx.x * kGenWaves + wave) * kWave + lane);
     bool valid = false;
     Ray nr;
+    uint8_t* px = nullptr;
+    uint32_t xy = 0;
+    int frame = 0;
     float vdir[3] = {0.f, 0.f, 1.f};
     if (id < p.total_rays) {
         const PixelRef r = locate(p, id);
         if (r.in_image) {
-            nr.frame = r.frame;
-            nr.xy = (uint32_t)r.x | ((uint32_t)r.y << 16);
-            nr.pix_off =
-                (uint32_t)(pixel_ptr(p, p.frames[r.frame], r) - p.frames[r.frame].rgba);
+            frame = r.frame;
+            xy = (uint32_t)r.x | ((uint32_t)r.y << 16);
+            px = pixel_ptr(p, p.frames[r.frame], r);
             setup_ray<FMA>(p, r, nr, vdir);
             if (nr.alive) {
                 valid = true;
             } else {
                 RayCounters z;  // a ray without a single sample
-                finish_ray<FMA, FULL>(p, nr, z);
+                finish_ray<FMA, FULL>(p, nr, z, px, xy, frame);
             }
         }
     }
@@ -1307,20 +1400,20 @@ __global__ __launch_bounds__(kWave* kGenWaves) void raygen_kernel(const KParams 
     const uint32_t slot =
         wave_base[wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_valid >> 32),
                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)m_valid, 0u));
-    const size_t cap = p.total_rays;
-    uint32_t* rb = p.ray_buf_rw + slot;
+    uint32_t* rb = ray_slot(p.ray_buf_rw, kRayWords + p.basis_words, slot);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        rb[(size_t)(0 + i) * cap] = f2u(nr.cen[i]);
-        rb[(size_t)(3 + i) * cap] = f2u(nr.dir[i]);
-        rb[(size_t)(6 + i) * cap] = f2u(nr.invdir[i]);
+        rb[(0 + i) * 64] = f2u(nr.cen[i]);
+        rb[(3 + i) * 64] = f2u(nr.dir[i]);
+        rb[(6 + i) * 64] = f2u(nr.invdir[i]);
     }
-    rb[(size_t)9 * cap] = f2u(nr.t);
-    rb[(size_t)10 * cap] = f2u(nr.tmax);
-    rb[(size_t)11 * cap] = f2u(nr.delta_scale);
-    rb[(size_t)12 * cap] = nr.xy;
-    rb[(size_t)13 * cap] = nr.pix_off;
-    rb[(size_t)14 * cap] = (uint32_t)nr.frame;
+    rb[9 * 64] = f2u(nr.t);
+    rb[10 * 64] = f2u(nr.tmax);
+    rb[11 * 64] = f2u(nr.delta_scale);
+    rb[12 * 64] = xy;
+    rb[13 * 64] = (uint32_t)reinterpret_cast<uint64_t>(px);
+    rb[14 * 64] = (uint32_t)(reinterpret_cast<uint64_t>(px) >> 32);
+    rb[15 * 64] = (uint32_t)frame;
     if (p.basis_words > 0) {
         // rt_core.cuh:96-103: basis of the view direction, zeroed outside basis_minmax
         float b[VR_MAX_BASIS];
@@ -1330,7 +1423,7 @@ __global__ __launch_bounds__(kWave* kGenWaves) void raygen_kernel(const KParams 
 #pragma unroll
         for (int i = 0; i < VR_MAX_BASIS; ++i)
             if (i < p.basis_words)
-                rb[(size_t)(kRayWords + i) * cap] =
+                rb[(kRayWords + i) * 64] =
                     f2u((i < p.basis_min || i > p.basis_max) ? 0.f : b[i]);
     }
 }
