@@ -339,3 +339,40 @@ def test_lookup_structure_geometries(torch_cuda, top_levels, brick_levels, fp_mo
     assert_parity(rgba_g, acc_g, rgba_o, acc_o)
     assert cnt_g == cnt
     assert np.array_equal(img.cpu().numpy(), rgba_o)
+
+
+@pytest.mark.parametrize("frame_group,super_block", [(1, 1), (2, 2), (3, 4), (0, 3), (4, 64)])
+def test_ray_order_is_scheduling_only(torch_cuda, frame_group, super_block):
+    """The ray-id order (frame groups x super-blocks of 8x8 pixel blocks, vr_kernels.hip locate())
+    decides which rays march together, never what they compute: a 5-pose batch of a ragged
+    image -- whole frames and 3-way tile shards with odd tile sizes -- must equal the oracle
+    under every order."""
+    torch = torch_cuda
+    from volrend_amd import api
+    tree = common.small_scene(depth=5, basis_dim=9, seed=1301)
+    w, h, f = 150, 107, 170.0
+    trs = [common.camera_for(pose_idx=i, size=64)[0] for i in range(5)]
+    want = [common.oracle_frame(tree, tr, w, h, f, 0)[0] for tr in trs]
+    t = api.N3Tree.from_synth(tree)
+    cam = api.Camera(w, h, f, f)
+    api.set_tuning(frame_group=frame_group, super_block=super_block)
+    try:
+        imgs = torch.zeros((5, h, w, 4), dtype=torch.uint8, device="cuda")
+        api.launch_renderer_batch(t, cam, trs, api.RenderOptions(), list(imgs), None, True)
+        world, tw, th = 3, 48, 24
+        sh0 = api.TileShard(tw, th, 0, world, compact=True)
+        nbytes = api.compact_bytes(w, h, sh0)
+        gathered = torch.zeros((world, 5, nbytes), dtype=torch.uint8, device="cuda")
+        for r in range(world):
+            api.launch_renderer_batch(t, cam, trs, api.RenderOptions(),
+                                      [gathered[r, i] for i in range(5)], None, True,
+                                      shard=api.TileShard(tw, th, r, world, compact=True))
+        outs = torch.zeros((5, h, w, 4), dtype=torch.uint8, device="cuda")
+        api.assemble_tiles_batch(outs, gathered, 5, w, h, sh0, torch.cuda.current_stream())
+        torch.cuda.synchronize()
+    finally:
+        api.set_tuning(frame_group=0, super_block=1)
+    for i in range(5):
+        assert np.array_equal(imgs[i].cpu().numpy(), want[i]), ("frame", i)
+        assert np.array_equal(outs[i].cpu().numpy(), want[i]), ("sharded", i)
+    t.free_device()

@@ -469,6 +469,46 @@ def launch_renderer(tree: N3Tree, cam: Camera, options: RenderOptions, image, de
     _abi.check(L.vr_render(tree.handle, C.byref(c), C.byref(o), C.byref(f), _stream_ptr(stream)))
 
 
+class PreparedBatch:
+    """The marshalled arguments of one ``vr_render_batch`` call.  Building them costs ~20 us of
+    Python per pose; a render loop that knows its poses up front (``volrend_headless``,
+    main_headless.cpp:207-225) builds them once and each ``launch`` is a single C call, so the
+    host never leaves the GPU idle between launches."""
+
+    def __init__(self, tree: N3Tree, cam: Camera, transforms, options: RenderOptions, images,
+                 offscreen: bool = True, *, accums=None, depths=None, pitch: int = 0,
+                 shard: TileShard | None = None, fp_mode: int = _abi.FP_STRICT, counters=None):
+        n = len(transforms)
+        if n != len(images):
+            raise ValueError("one image per pose")
+        L = _abi.lib()
+        self.tree, self.n = tree, n
+        self.cams = (_abi.VrCamera * n)()
+        self.frames = (_abi.VrFrame * n)()
+        self._keep = (images, accums, depths, counters)  # the buffers must outlive the launch
+        for i in range(n):
+            cam.transform = np.asarray(transforms[i], dtype=np.float32)
+            self.cams[i] = cam.to_c()
+            f = self.frames[i]
+            L.vr_default_frame(C.byref(f))
+            f.rgba = _ptr(images[i])
+            f.pitch = pitch
+            f.depth = _ptr(depths[i]) if depths else None
+            f.accum = _ptr(accums[i]) if accums else None
+            f.offscreen = 1 if offscreen else 0
+            f.fp_mode = fp_mode
+            f.counters = _ptr(counters[i]) if counters else None
+            if shard is not None:
+                f.tile_w, f.tile_h, f.rank, f.world = (shard.tile_w, shard.tile_h, shard.rank,
+                                                       shard.world)
+                f.layout = _abi.LAYOUT_COMPACT if shard.compact else _abi.LAYOUT_FRAME
+        self.opts = options.to_c()
+
+    def launch(self, stream=None) -> None:
+        _abi.check(_abi.lib().vr_render_batch(self.tree.handle, self.n, self.cams,
+                                              C.byref(self.opts), self.frames, _stream_ptr(stream)))
+
+
 def launch_renderer_batch(tree: N3Tree, cam: Camera, transforms, options: RenderOptions, images,
                           stream=None, offscreen: bool = True, *, accums=None, depths=None,
                           pitch: int = 0, shard: TileShard | None = None,
@@ -478,30 +518,8 @@ def launch_renderer_batch(tree: N3Tree, cam: Camera, transforms, options: Render
     The pose loop of ``volrend_headless`` (main_headless.cpp:207-225) with the
     poses known up front; intrinsics / options / sharding are shared.  ``counters``:
     optional list of device int64[7] tensors (instrumented flavour)."""
-    n = len(transforms)
-    if n != len(images):
-        raise ValueError("one image per pose")
-    L = _abi.lib()
-    cams = (_abi.VrCamera * n)()
-    frames = (_abi.VrFrame * n)()
-    for i in range(n):
-        cam.transform = np.asarray(transforms[i], dtype=np.float32)
-        cams[i] = cam.to_c()
-        f = frames[i]
-        L.vr_default_frame(C.byref(f))
-        f.rgba = _ptr(images[i])
-        f.pitch = pitch
-        f.depth = _ptr(depths[i]) if depths else None
-        f.accum = _ptr(accums[i]) if accums else None
-        f.offscreen = 1 if offscreen else 0
-        f.fp_mode = fp_mode
-        f.counters = _ptr(counters[i]) if counters else None
-        if shard is not None:
-            f.tile_w, f.tile_h, f.rank, f.world = (shard.tile_w, shard.tile_h, shard.rank,
-                                                   shard.world)
-            f.layout = _abi.LAYOUT_COMPACT if shard.compact else _abi.LAYOUT_FRAME
-    o = options.to_c()
-    _abi.check(L.vr_render_batch(tree.handle, n, cams, C.byref(o), frames, _stream_ptr(stream)))
+    PreparedBatch(tree, cam, transforms, options, images, offscreen, accums=accums, depths=depths,
+                  pitch=pitch, shard=shard, fp_mode=fp_mode, counters=counters).launch(stream)
 
 
 def set_tuning(**kw) -> None:

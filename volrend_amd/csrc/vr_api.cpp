@@ -35,7 +35,8 @@ struct Tuning {
     int refill_min = 24;
     int waves_per_cu = 0;   // 0: what the kernel flavour fits (vr_kernels.hip waves_per_cu<>)
     int shade_min = 48;
-    int frame_minor = 1;
+    int frame_group = 0;   // poses per ray-order group (0 = all poses of the launch, 1 = frame-major)
+    int super_block = 1;   // 8x8 blocks per super-block edge in the ray order
     int xcd_queues = 1;
     int chunk_max = 4096;
     int top_levels = 0;    // lookup structure of trees uploaded from now on (vr_kernels.hip); 0 = auto
@@ -48,7 +49,8 @@ Tuning& tuning() {
         if (const char* e = getenv("VR_REFILL_MIN")) x.refill_min = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_WAVES_PER_CU")) x.waves_per_cu = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("VR_SHADE_MIN")) x.shade_min = atoi(e) < 1 ? 1 : atoi(e);
-        if (const char* e = getenv("VR_FRAME_MINOR")) x.frame_minor = atoi(e) != 0;
+        if (const char* e = getenv("VR_FRAME_GROUP")) x.frame_group = atoi(e) < 0 ? 0 : atoi(e);
+        if (const char* e = getenv("VR_SUPER_BLOCK")) x.super_block = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_XCD_QUEUES")) x.xcd_queues = atoi(e) != 0;
         if (const char* e = getenv("VR_CHUNK_MAX")) x.chunk_max = atoi(e) < 64 ? 64 : (atoi(e) & ~63);
         if (const char* e = getenv("VR_TOP_LEVELS")) x.top_levels = atoi(e);
@@ -747,7 +749,8 @@ int vr_set_tuning(const char* key, int value) {
     else if (!strcmp(key, "refill_min")) tn.refill_min = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "waves_per_cu")) tn.waves_per_cu = value < 0 ? 0 : (value > 32 ? 32 : value);
     else if (!strcmp(key, "shade_min")) tn.shade_min = value < 1 ? 1 : (value > 64 ? 64 : value);
-    else if (!strcmp(key, "frame_minor")) tn.frame_minor = value != 0;
+    else if (!strcmp(key, "frame_group")) tn.frame_group = value < 0 ? 0 : value;
+    else if (!strcmp(key, "super_block")) tn.super_block = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "xcd_queues")) tn.xcd_queues = value != 0;
     else if (!strcmp(key, "chunk_max")) tn.chunk_max = value < 64 ? 64 : (value & ~63);
     else if (!strcmp(key, "top_levels")) tn.top_levels = value;
@@ -909,7 +912,8 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.march_max = tn.march_max;
     k.refill_min = tn.refill_min;
     k.shade_min = tn.shade_min;
-    k.frame_minor = tn.frame_minor;
+    k.frame_group = tn.frame_group < 1 || tn.frame_group > n_frames ? n_frames : tn.frame_group;
+    k.super_block = tn.super_block;
     // launch slot: per-launch scratch in device memory (ring, see LaunchSlot)
     hipStream_t hs = static_cast<hipStream_t>(stream);
     std::lock_guard<std::mutex> guard(t->launch_mutex);

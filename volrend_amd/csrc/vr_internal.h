@@ -94,7 +94,8 @@ struct KParams {
     int32_t shade_min;           // shade once this many lanes have queued colour work
     int32_t instrumented;        // any frame carries counters -> FULL flavour
     int32_t any_accum;           // some frame of the launch asks for its fp32 accumulators
-    int32_t frame_minor;         // ray-id order: pixel block major, frame minor
+    int32_t frame_group;         // ray-id order: frames per group (block major, frame minor inside)
+    int32_t super_block;         // ray-id order: blocks of a tile visited in SxS super-blocks
     uint32_t* status;            // device word: bit0 = iteration cap hit
     unsigned long long* sched_stats;  // 8 x u64 scheduling tallies (instrumented flavours)
     // distinct-line meter (instrumented flavours, vr_touch_enable): one bit per 128-byte line of

@@ -614,26 +614,50 @@ struct PixelRef {
 
 __device__ __forceinline__ PixelRef locate(const KParams& p, uint32_t id) {
     PixelRef r;
-    // Ray-id order: 8x8 pixel block major, FRAME minor (frame_minor = 1): the same pixel block
-    // of consecutive poses of the batch sits in consecutive ids, so rays that walk through
-    // (nearly) the same leaves are generated, queued and marched together and share
-    // cache lines.  frame_minor = 0 is plain frame-major order.
+    // Ray-id order (scheduling only; consecutive ids are generated, queued and marched together):
+    // the frames of the launch are taken in groups of p.frame_group consecutive poses; within a
+    // group the 8x8 pixel block is the major index and the FRAME the minor one, so the same
+    // block of neighbouring poses -- rays that walk through nearly the same leaves -- sits in
+    // consecutive ids; the blocks of a tile are visited super-block by super-block
+    // (p.super_block x p.super_block blocks, row-major inside), so that a wave's chunk of ids
+    // covers a compact screen region instead of a thin strip.
     const uint32_t blk = id >> 6;
     const int32_t lane = (int32_t)(id & 63u);
-    int32_t wb;
-    if (p.frame_minor) {
-        wb = (int32_t)(blk / (uint32_t)p.n_frames);
-        r.frame = (int32_t)(blk - (uint32_t)wb * (uint32_t)p.n_frames);
-    } else {
-        r.frame = (int32_t)(blk / (uint32_t)p.n_wave_blocks);
-        wb = (int32_t)(blk - (uint32_t)r.frame * (uint32_t)p.n_wave_blocks);
-    }
+    const uint32_t G = (uint32_t)p.frame_group, nwb = (uint32_t)p.n_wave_blocks;
+    const uint32_t grp = blk / (nwb * G), rem = blk - grp * nwb * G;
+    const uint32_t left = (uint32_t)p.n_frames - grp * G, gsz = left < G ? left : G;
+    const int32_t wb = (int32_t)(rem / gsz);
+    r.frame = (int32_t)(grp * G + (rem - (uint32_t)wb * gsz));
     // wave block -> local tile -> frame tile -> pixel
     r.k = wb / p.wblocks_per_tile;
     const int32_t sub = wb - r.k * p.wblocks_per_tile;
     const int32_t tile = r.k * p.world + p.rank;
     const int32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-    const int32_t sy = sub / p.wblocks_per_tile_x, sx = sub - sy * p.wblocks_per_tile_x;
+    int32_t sx, sy;
+    const int32_t nbx = p.wblocks_per_tile_x;
+    if (p.super_block <= 1) {
+        sy = sub / nbx;
+        sx = sub - sy * nbx;
+    } else {  // ragged edges: the last super-row / super-column is simply shorter
+        const int32_t S = p.super_block, nby = p.wblocks_per_tile / nbx;
+        const int32_t per_sr = S * nbx, full_sr = nby / S;
+        int32_t sr = sub / per_sr, in_sr = sub - sr * per_sr, rows = S;
+        if (sr >= full_sr) {
+            sr = full_sr;
+            in_sr = sub - full_sr * per_sr;
+            rows = nby - full_sr * S;
+        }
+        const int32_t per_sc = rows * S, full_sc = nbx / S;
+        int32_t sc = in_sr / per_sc, in_sc = in_sr - sc * per_sc, cols = S;
+        if (sc >= full_sc) {
+            sc = full_sc;
+            in_sc = in_sr - full_sc * per_sc;
+            cols = nbx - full_sc * S;
+        }
+        const int32_t iy = in_sc / cols;
+        sx = sc * S + (in_sc - iy * cols);
+        sy = sr * S + iy;
+    }
     r.lx = sx * 8 + (lane & 7);
     r.ly = sy * 8 + (lane >> 3);
     r.x = tx * p.tile_w + r.lx;
