@@ -258,7 +258,7 @@ def main():
         api.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
 
     # per-GPU work per launch shrinks with the tile shard: keep it up with more poses per launch
-    B = max(1, min(args.batch * (1 if args.mode == "replicas" else world), 128))
+    B = max(1, min(args.batch * (1 if args.mode == "replicas" else world), _abi.MAX_BATCH))
     tile_h = max(8, (args.tile_rows // 8) * 8)
     tile_w = (W + 7) // 8 * 8
     sharded = use_dist and not replicas

@@ -305,7 +305,7 @@ def test_random_configurations_bit_exact(torch_cuda, fp_mode):
 
 
 @pytest.mark.parametrize("fp_mode", [0, 1])
-@pytest.mark.parametrize("top_levels,brick_levels", [(1, 1), (1, 3), (2, 2), (2, 3), (3, 3), (4, 1),
+@pytest.mark.parametrize("top_levels,brick_levels", [(1, 1), (1, 3), (1, 4), (2, 2), (2, 3), (2, 4), (3, 3), (3, 4), (4, 1),
                                                      (5, 2), (6, 3), (8, 3)])
 def test_lookup_structure_geometries(torch_cuda, top_levels, brick_levels, fp_mode):
     """The N == 2 lookup structure (top grid of 2^G0 cells per axis + bricks of 2^BL entries per

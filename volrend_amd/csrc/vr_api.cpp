@@ -465,7 +465,7 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
         G0 = tn.top_levels > 0 ? tn.top_levels : (max_depth + 1 - 3 < 6 ? 6 : max_depth + 1 - 3);
         if (G0 > 8) G0 = 8;
         if (G0 > max_depth + 1) G0 = max_depth + 1;  // deepest leaf depth
-        BL = tn.brick_levels < 1 ? 1 : (tn.brick_levels > 3 ? 3 : tn.brick_levels);
+        BL = tn.brick_levels < 1 ? 1 : (tn.brick_levels > 4 ? 4 : tn.brick_levels);
         if (BL > max_depth + 1 - G0) BL = max_depth + 1 - G0;  // 0: the top grid resolves every leaf
         // the kernel addresses brick entries with 32-bit byte offsets: keep the brick array < 4 GB
         uint64_t n_roots = 0;

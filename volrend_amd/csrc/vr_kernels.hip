@@ -164,14 +164,14 @@ __device__ __forceinline__ void precalc_basis(const KParams& p, const float* dir
 //   bricks[n_bricks * 8^BL]  u32   (default BL = 3: 512 entries = 2 KB per brick) entry per
 //        cell of the 2^BL-per-axis subdivision of a top cell:
 //        bit31 = 1 : inside one leaf of depth d = G0 + 1 + drel:
-//                    leaf | drel << 26 | delta << 19 | slot << 16 | sigma(fp16), where the leaf
+//                    leaf | drel << 29 | delta << 19 | slot << 16 | sigma(fp16), where the leaf
 //                    is child `slot` of node root + delta (the brick root's descendants of the
-//                    next BL - 1 levels are numbered right behind it: delta <= 72)
+//                    next BL - 1 levels are numbered right behind it: delta <= 8 + 64 + 512)
 //        bit31 = 0 : an internal node of level G0 + BL: its index; the walk continues there
 //                    with one child-word load per level.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kLeafBit = 0x80000000u;
-constexpr int kMaxBrickLevels = 3;   // delta field: 8 + 64 nodes below a brick root
+constexpr int kMaxBrickLevels = 4;   // delta field (10 bits): 8 + 64 + 512 nodes below a brick root
 
 // Distinct-line meter of the instrumented flavours (SURVEY.md 8(d) "B_unique"): marks the 128-byte
 // line(s) an access of `bytes` bytes at byte offset `off` of array `which` touches.
@@ -270,8 +270,8 @@ __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* 
         if (COUNT) touch(p, TOUCH_BRICKS, (uint64_t)entry * 4u, 4u);
         w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.bricks) + (entry << 2));
         if (w & kLeafBit) {
-            d = (int)(g0 + 1u + __builtin_amdgcn_ubfe(w, 26u, 2u));
-            id = (id << 3) + __builtin_amdgcn_ubfe(w, 16u, 10u);  // (root + delta) * 8 + slot
+            d = (int)(g0 + 1u + __builtin_amdgcn_ubfe(w, 29u, 2u));
+            id = (id << 3) + __builtin_amdgcn_ubfe(w, 16u, 13u);  // (root + delta) * 8 + slot
         } else {
             // deeper than the brick: one child word per level (32-bit byte offsets: the node
             // array is < 4 GB, checked at upload)
@@ -1706,8 +1706,8 @@ __global__ void build_bricks_kernel(const uint32_t* nodes, const int32_t* brick_
         const uint32_t w = nodes[(uint64_t)node * 8u + slot];
         if (w & kLeafBit) {
             const uint32_t delta = node - root;
-            if (delta > 127u) atomicOr(error_flag, 2u);  // numbering contract broken
-            bricks[gid] = kLeafBit | ((uint32_t)k << 26) | ((delta & 127u) << 19) | (slot << 16) |
+            if (delta > 1023u) atomicOr(error_flag, 2u);  // numbering contract broken
+            bricks[gid] = kLeafBit | ((uint32_t)k << 29) | ((delta & 1023u) << 19) | (slot << 16) |
                           (w & 0xFFFFu);
             return;
         }
