@@ -43,6 +43,11 @@ def main():
     out = {"config": name, "poses": len(poses)}
     out["timing_only"] = run(common)
     out["timing_only_batch64"] = run(common + ["--batch", "64"])
+    # the native tile-shard path on this one-GPU box: 1 rank through RCCL (ncclCommInitAll + a
+    # grouped self send/recv per launch), and a 2-rank REHEARSAL sharing the GPU (never a measurement
+    # of scaling: both ranks compete for the same chip)
+    out["gpus1_rccl_self"] = run(common + ["--batch", "64", "--gpus", "1"])
+    out["gpus2_shared_gpu_rehearsal"] = run(common + ["--batch", "64", "--gpus", "2", "--share_gpu"])
     out["write_png"] = run(common + ["-o", os.path.join(work, "out")])
     out["png_files"] = len(os.listdir(os.path.join(work, "out")))
     shutil.rmtree(work, ignore_errors=True)
