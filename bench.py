@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--config", default="C1", choices=["C0", "C1", "C1r", "C1t", "C2", "C3"])
+    ap.add_argument("--config", default="C1", choices=["C0", "C1", "C1r", "C1t", "C2", "C3", "X1", "X3"])
     ap.add_argument("--fp", default="strict", choices=["strict", "fma"])
     ap.add_argument("--tile-rows", type=int, default=8, help="rows per interleaved screen tile")
     ap.add_argument("--batch", type=int, default=64,

@@ -37,6 +37,7 @@ struct Tuning {
     int shade_min = 48;
     int frame_group = 0;   // poses per ray-order group (0 = all poses of the launch, 1 = frame-major)
     int super_block = 1;   // 8x8 blocks per super-block edge in the ray order
+    int records_nt = -1;   // record stream non-temporal: -1 = by lookup-structure size, 0 / 1 = forced
     int xcd_queues = 1;
     int chunk_max = 4096;
     int top_levels = 0;    // lookup structure of trees uploaded from now on (vr_kernels.hip); 0 = auto
@@ -51,6 +52,7 @@ Tuning& tuning() {
         if (const char* e = getenv("VR_SHADE_MIN")) x.shade_min = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_FRAME_GROUP")) x.frame_group = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("VR_SUPER_BLOCK")) x.super_block = atoi(e) < 1 ? 1 : atoi(e);
+        if (const char* e = getenv("VR_RECORDS_NT")) x.records_nt = atoi(e);
         if (const char* e = getenv("VR_XCD_QUEUES")) x.xcd_queues = atoi(e) != 0;
         if (const char* e = getenv("VR_CHUNK_MAX")) x.chunk_max = atoi(e) < 64 ? 64 : (atoi(e) & ~63);
         if (const char* e = getenv("VR_TOP_LEVELS")) x.top_levels = atoi(e);
@@ -751,6 +753,7 @@ int vr_set_tuning(const char* key, int value) {
     else if (!strcmp(key, "shade_min")) tn.shade_min = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "frame_group")) tn.frame_group = value < 0 ? 0 : value;
     else if (!strcmp(key, "super_block")) tn.super_block = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (!strcmp(key, "records_nt")) tn.records_nt = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "xcd_queues")) tn.xcd_queues = value != 0;
     else if (!strcmp(key, "chunk_max")) tn.chunk_max = value < 64 ? 64 : (value & ~63);
     else if (!strcmp(key, "top_levels")) tn.top_levels = value;
@@ -909,6 +912,10 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.instrumented = instrumented ? 1 : 0;
     k.any_accum = any_accum ? 1 : 0;
     const Tuning& tn = tuning();
+    // lookup structure (top + bricks) beyond 4x the aggregate L2 (8 x 4 MiB on MI355X): the record
+    // stream would keep evicting it -- see the DMA loads in vr_kernels.hip
+    k.records_nt = tn.records_nt >= 0 ? tn.records_nt
+                                      : (t->array_bytes[2] + t->array_bytes[3] > (128ull << 20));
     k.march_max = tn.march_max;
     k.refill_min = tn.refill_min;
     k.shade_min = tn.shade_min;

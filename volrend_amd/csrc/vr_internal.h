@@ -94,6 +94,7 @@ struct KParams {
     int32_t shade_min;           // shade once this many lanes have queued colour work
     int32_t instrumented;        // any frame carries counters -> FULL flavour
     int32_t any_accum;           // some frame of the launch asks for its fp32 accumulators
+    int32_t records_nt;          // record DMA loads carry the non-temporal hint (large lookup structures)
     int32_t frame_group;         // ray-id order: frames per group (block major, frame minor inside)
     int32_t super_block;         // ray-id order: blocks of a tile visited in SxS super-blocks
     uint32_t* status;            // device word: bit0 = iteration cap hit

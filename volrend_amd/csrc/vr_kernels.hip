@@ -39,6 +39,9 @@ constexpr int kWave = 64;
 #ifndef VR_SH16_WAVES
 #define VR_SH16_WAVES 5
 #endif
+#ifndef VR_SH9_WAVES
+#define VR_SH9_WAVES 6  // (7 fits the LDS but needs 72 VGPRs: scratch)
+#endif
 #ifndef VR_PAIRED_CHANNELS
 #define VR_PAIRED_CHANNELS 0  // 1: strict model, channels 0/1 accumulate in a register pair (v_pk_add_f32):
                                // -15 VALU per SH16 round but +5 live registers = scratch at 96 VGPRs
@@ -898,6 +901,34 @@ typedef __attribute__((address_space(3))) void* vr_lptr_t;
 // 64-frame one, for a second register and a 64-bit funnel shift per push.)
 constexpr int kOwnerQ = 4;
 
+// The record requests of one pass of a shade round (see Stage): lane l fetches 16-byte chunk
+// l % V of record l / V of its instruction, straight into the stage rows.  NT = the non-temporal
+// cache policy (an immediate of the instruction, hence a template parameter).
+template <int BASIS, bool NT>
+__device__ __forceinline__ void issue_records(const KParams& p, char* stage, const uint32_t* it_leaf,
+                                              uint32_t ring_head, int lane, int n, int pass) {
+    using ST = Stage<BASIS>;
+#pragma unroll
+    for (int k = 0; k < ST::kInstr; ++k) {
+        const int rin = k * ST::kPerInstr + lane / ST::kVec;  // record within the pass
+        const int item = pass * ST::kPass + rin;
+        if (lane < ST::kPerInstr * ST::kVec && rin < ST::kPass && item < n) {
+#if VR_ABLATE == 5   // timing experiment only: every record comes from a 128 KB window
+            const uint32_t leaf = it_leaf[(ring_head + (uint32_t)item) & (kRing - 1)] & 0x3FFu;
+#else
+            const uint32_t leaf = it_leaf[(ring_head + (uint32_t)item) & (kRing - 1)];
+#endif
+            const char* src = reinterpret_cast<const char*>(p.leaves) +
+                              (uint64_t)leaf * (uint32_t)(p.leaf_stride_h * 2) + (lane % ST::kVec) * 16;
+#if VR_ABLATE != 4   // 4 = timing experiment only: no record fetch at all
+            __builtin_amdgcn_global_load_lds((vr_gptr_t)src,
+                                             (vr_lptr_t)(stage + k * ST::kPerInstr * ST::kRow), 16, 0,
+                                             NT ? 2 /* nt */ : 0);
+#endif
+        }
+    }
+}
+
 // Register budget of the production (FAST) flavours, from their natural register use: SH16 <= 80
 // VGPRs (6 waves per SIMD -- with its 6.4 KB of LDS that is 24 waves per CU), SH9 <= 72 (7),
 // SH25 <= 128 (4: it gathers its 25 basis values up front), the small records 8.  The instrumented / lobe / generic flavours keep their
@@ -905,7 +936,7 @@ constexpr int kOwnerQ = 4;
 template <int BASIS, int MODE>
 constexpr int min_waves_per_eu() {
     if (MODE != MODE_FAST) return BASIS == BASIS_25 ? 3 : 4;  // SH25 + counters needs > 128 VGPRs
-    const int want = BASIS == BASIS_25 ? 4 : BASIS == BASIS_16 ? VR_SH16_WAVES : BASIS == BASIS_9 ? 7 : 8;
+    const int want = BASIS == BASIS_25 ? 4 : BASIS == BASIS_16 ? VR_SH16_WAVES : BASIS == BASIS_9 ? VR_SH9_WAVES : 8;
     return want < VR_MIN_WAVES_PER_EU ? want : VR_MIN_WAVES_PER_EU;
 }
 // Waves one CU holds of a flavour: the register bound above or the LDS bound (512-byte granules).
@@ -1024,26 +1055,17 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
 #pragma unroll
             for (int pass = 0; pass < ST::kPasses; ++pass) {
                 if (pass * ST::kPass < n) {  // wave-uniform
-#pragma unroll
-                    for (int k = 0; k < ST::kInstr; ++k) {
-                        const int rin = k * ST::kPerInstr + lane / ST::kVec;  // record within the pass
-                        const int item = pass * ST::kPass + rin;
-                        if (lane < ST::kPerInstr * ST::kVec && rin < ST::kPass && item < n) {
-#if VR_ABLATE == 5   // timing experiment only: every record comes from a 128 KB window
-                            const uint32_t leaf =
-                                it_leaf[(ring_head + (uint32_t)item) & (kRing - 1)] & 0x3FFu;
-#else
-                            const uint32_t leaf = it_leaf[(ring_head + (uint32_t)item) & (kRing - 1)];
-#endif
-                            const char* src = reinterpret_cast<const char*>(p.leaves) +
-                                              (uint64_t)leaf * (uint32_t)(p.leaf_stride_h * 2) +
-                                              (lane % ST::kVec) * 16;
-#if VR_ABLATE != 4   // 4 = timing experiment only: no record fetch at all
-                            __builtin_amdgcn_global_load_lds(
-                                (vr_gptr_t)src, (vr_lptr_t)(stage + k * ST::kPerInstr * ST::kRow), 16, 0, 0);
-#endif
-                        }
-                    }
+                    // Cache policy of the record stream (launch-uniform, chosen at upload): by
+                    // default the records allocate in L2 like any load -- neighbouring rays
+                    // re-use a quarter of them; when the lookup structure is much larger than
+                    // the L2s, the stream is marked non-temporal so that it stops evicting the
+                    // top / brick lines every sample needs (C3: -11 % time; C1-class trees:
+                    // +8 %, hence the switch).  The policy is an immediate of the instruction,
+                    // so the issue loop exists twice.
+                    if (p.records_nt)
+                        issue_records<BASIS, true>(p, stage, it_leaf, ring_head, lane, n, pass);
+                    else
+                        issue_records<BASIS, false>(p, stage, it_leaf, ring_head, lane, n, pass);
                     __syncthreads();  // the DMAs have landed (vmcnt(0)) and are visible
                     TL_ADD(tl_shade_load);
                     // (one pass: ALL lanes run the arithmetic -- an owner lane without an item

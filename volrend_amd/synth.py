@@ -41,6 +41,11 @@ CONFIGS = {
     "C1t": dict(depth=9, fmt="SH", basis_dim=16, seed=1002, width=800, height=800, focal=1111.111,
                 sigma=(5.0, 200.0), n_shapes=64, shape_size=(0.3, 0.7), shell_leaves=2.5,
                 center_range=1.3),
+    # cache-policy experiments (tools/variant_cfg.sh): C1's topology with SH9 records, C3's with SH16
+    "X1": dict(depth=9, fmt="SH", basis_dim=9, seed=1002, width=800, height=800, focal=1111.111,
+               sigma=(5.0, 200.0), n_shapes=12, shape_size=(0.5, 1.0), shell_leaves=7.5),
+    "X3": dict(depth=10, fmt="SH", basis_dim=16, seed=1004, width=1920, height=1080, focal=1166.0,
+               sigma=(5.0, 200.0), n_shapes=12, shape_size=(0.5, 1.0), shell_leaves=4.0),
     "C2": dict(depth=9, fmt="SH", basis_dim=25, seed=1003, width=800, height=800, focal=1111.111,
                sigma=(1.0, 10.0), n_shapes=12, shape_size=(0.5, 1.0), shell_leaves=7.5),
     "C3": dict(depth=10, fmt="SH", basis_dim=9, seed=1004, width=1920, height=1080, focal=1166.0,
