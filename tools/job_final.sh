@@ -18,6 +18,9 @@ timeout 300 python bench.py --readback --no-cpu-baseline > $O/${R}_bench_C1_read
 VOLREND_FORCE_GATHER=1 timeout 300 python bench.py --no-cpu-baseline > $O/${R}_bench_C1_forced_gather.json 2>/dev/null
 bash tools/launch_sweep.sh $R > /dev/null 2>&1; cp gpurun_out/sweep_$R.jsonl $O/${R}_launch_sweep.jsonl
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o stats --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 128 --warmup 64 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/prof_bench.json 2> $GRAFT_REPO_ROOT/$O/prof.log ); cp $O/prof/stats_kernel_stats.csv $O/${R}_final_kernel_stats.csv
+VR_TIMELINE=1 VOLREND_HIP_LIB=$PWD/volrend_amd/libvolrend_hip_tl.so timeout 300 python bench.py --no-cpu-baseline 2>&1 >/dev/null | grep timeline > $O/${R}_timeline.txt
+for c in C2 C3; do VR_TIMELINE=1 VOLREND_HIP_LIB=$PWD/volrend_amd/libvolrend_hip_tl.so timeout 600 python bench.py --config $c --no-cpu-baseline 2>&1 >/dev/null | grep timeline | sed -e "s/^/$c: /" >> $O/${R}_timeline.txt; done
+bash tools/kernel_resources.sh > $O/${R}_kernel_resources.txt 2>&1
 timeout 900 python tools/cli_bench.py > $O/${R}_cli_bench.json 2> $O/cli_bench.log
 python - <<PY
 import json,glob
