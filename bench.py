@@ -124,6 +124,31 @@ def cpu_baseline(tree, transforms, width, height, focal, budget_s=8.0):
     return out
 
 
+def committed_traffic(config: str, fp: str, profiles_dir: str | None = None, have_hash: str | None = None):
+    """(L2<->fabric bytes per frame, provenance) from the newest profiles/r*_traffic_<config>.json
+    whose recorded kernel-source hash equals the sources this run was built from; (None, reason)
+    when there is no measurement or it is stale."""
+    import glob
+    if have_hash is None:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from measure_traffic import kernel_source_hash
+        have_hash = kernel_source_hash()
+    profiles_dir = profiles_dir or os.path.join(ROOT, "profiles")
+    reason = f"no profiles/r*_traffic_{config}.json"
+    for tpath in sorted(glob.glob(os.path.join(profiles_dir, f"r*_traffic_{config}.json")), reverse=True):
+        tj = json.load(open(tpath))
+        rel = os.path.join("profiles", os.path.basename(tpath))
+        if tj.get("fp_mode") != fp or "read_bytes_per_frame" not in tj:
+            continue
+        if tj.get("kernel_source_sha256") != have_hash:
+            reason = f"{rel} is STALE (kernel sources changed since it was measured)"
+            continue
+        return (tj["read_bytes_per_frame"] + tj.get("write_bytes_per_frame", 0.0),
+                f"{rel}: rocprofv3 --pmc passes at {tj['frames_per_launch']} frames per launch, "
+                f"TCC_EA0_RDREQ_128B*128 + _64B*64 + _32B*32 + WRITE_SIZE, kernel source hash verified")
+    return None, reason
+
+
 def rtfrag_baseline(timeout_s=240):
     """BASELINE config C0 next to the GPU number (north_star): the reference's GLSL backend
     (shaders/rt.frag, its no-CUDA shader_renderer path) on a software GL rasteriser on THIS
@@ -440,27 +465,9 @@ def main():
     # it still matches the sources this run was built from; otherwise null, and the reason.
     traffic, traffic_src = None, None
     if world == 1:
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        from measure_traffic import kernel_source_hash
-        have = kernel_source_hash()
-        import glob as _glob
-        cands = sorted(_glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{args.config}.json")),
-                       reverse=True)
-        traffic_src = f"no profiles/r*_traffic_{args.config}.json"
-        for tpath in cands:
-            tj = json.load(open(tpath))
-            rel = os.path.relpath(tpath, ROOT)
-            if tj.get("fp_mode") != args.fp or "read_bytes_per_frame" not in tj:
-                continue
-            if tj.get("kernel_source_sha256") != have:
-                traffic_src = f"{rel} is STALE (kernel sources changed since it was measured)"
-                continue
-            traffic = int((tj["read_bytes_per_frame"] + tj.get("write_bytes_per_frame", 0.0)) *
-                          K / n_launch)
-            traffic_src = (f"{rel}: rocprofv3 --pmc passes at {tj['frames_per_launch']} frames per "
-                           f"launch, TCC_EA0_RDREQ_128B*128 + _64B*64 + _32B*32 + WRITE_SIZE, kernel "
-                           f"source hash verified")
-            break
+        per_frame, traffic_src = committed_traffic(args.config, args.fp)
+        if per_frame is not None:
+            traffic = int(per_frame * K / n_launch)
 
     if rank == 0:
         # replicas: every rank rendered its own K frames; tile mode: the K frames were shared

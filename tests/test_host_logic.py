@@ -9,6 +9,8 @@ from tests import common
 
 from volrend_amd import api, synth, tiles
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_data_format_parse():
     # DataFormat::parse, src/n3tree.cpp:55-78
@@ -128,3 +130,32 @@ def test_tile_shard_round_trip(w, h, tw, th, world):
     # agrees with the C ABI's buffer size
     from volrend_amd import _abi
     assert _abi.lib().vr_compact_bytes(w, h, tw, th, world) == n * 4
+
+
+def test_bench_reports_traffic_only_for_the_sources_it_was_measured_on(tmp_path):
+    """bench.py's roofline.traffic comes from a committed PMC measurement; it must vanish (with the
+    reason) the moment the kernel sources no longer hash to what the measurement recorded."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = {"config": "C1", "fp_mode": "strict", "frames_per_launch": 64,
+           "read_bytes_per_frame": 1.0e9, "write_bytes_per_frame": 5.0e6,
+           "kernel_source_sha256": "abc"}
+    (tmp_path / "r07_traffic_C1.json").write_text(json.dumps(rec))
+    (tmp_path / "r03_traffic_C1.json").write_text(json.dumps(dict(rec, kernel_source_sha256="old",
+                                                                    read_bytes_per_frame=2.0e9)))
+    got, why = bench.committed_traffic("C1", "strict", str(tmp_path), have_hash="abc")
+    assert got == 1.005e9 and "r07_traffic_C1.json" in why and "verified" in why
+    got, why = bench.committed_traffic("C1", "strict", str(tmp_path), have_hash="old")
+    assert got == 2.005e9 and "r03_traffic_C1.json" in why      # an older file that still matches
+    got, why = bench.committed_traffic("C1", "strict", str(tmp_path), have_hash="new")
+    assert got is None and "STALE" in why
+    got, why = bench.committed_traffic("C1", "fma", str(tmp_path), have_hash="abc")
+    assert got is None
+    got, why = bench.committed_traffic("C9", "strict", str(tmp_path), have_hash="abc")
+    assert got is None and "no profiles" in why
+    # the real hash covers the kernel sources and the build flags, and is stable
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from measure_traffic import kernel_source_hash
+    assert kernel_source_hash() == kernel_source_hash() and len(kernel_source_hash()) == 64
