@@ -42,8 +42,13 @@ class GatherPipeline:
         self.sizes[j] = n
         if not self.collective:
             return
-        self.works[j] = self.dist.gather(self.bufs[j % 2], self.gathered[j % 2], dst=0,
-                                         async_op=True)
+        # only the n frames of this launch travel (row-sliced views of the [batch, bytes] buffers
+        # are contiguous); a short last launch does not pay for the whole batch
+        send = self.bufs[j % 2][:n] if getattr(self.bufs[j % 2], "ndim", 1) > 1 else self.bufs[j % 2]
+        recv = None
+        if self.rank == 0:
+            recv = [g[:n] if getattr(g, "ndim", 1) > 1 else g for g in self.gathered[j % 2]]
+        self.works[j] = self.dist.gather(send, recv, dst=0, async_op=True)
 
     def retire(self, j: int, assemble) -> None:
         """Wait for launch j's gather; rank 0 calls ``assemble(j, gathered_list, n)``.
