@@ -364,13 +364,11 @@ def main():
         timing["events"] = events
         return pipe.run(n_steps, B, render, assemble, first)
 
-    # ---- warm-up (untimed) ---------------------------------------------------
-    # W untimed steps; at least one full-size launch per launch stream so that every launch slot
-    # the timed region will use owns its ray buffer (the library grows it on first use -- a
-    # blocking multi-GB hipMalloc that must not land inside the timed region).
-    n_warm = run(args.warmup, 0)
-    if args.warmup < n_streams * B:
-        run(n_streams * B, args.warmup)
+    # ---- slot sizing (untimed) -------------------------------------------------
+    # one full-size launch per launch stream, so that every launch slot the timed region will use
+    # owns its ray buffer (the library grows it on first use -- a blocking multi-GB hipMalloc that
+    # must not land inside the timed region)
+    run(n_streams * B, 0)
     torch.cuda.synchronize()
 
     # ---- algorithmic bytes: instrumented flavour, outside the timed region -----
@@ -418,6 +416,11 @@ def main():
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for _ in range(n_launch)]
     prepare(args.warmup, K)
+    # ---- W untimed warm-up steps, directly in front of the timed ones (everything that is
+    # neither warm-up nor timed -- counters, B_unique -- has run before: the chip enters the timed
+    # region the way a render loop in progress would find it)
+    if args.warmup > 0:
+        run(args.warmup, 0)
     barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
