@@ -436,7 +436,8 @@ def main():
             f"{n}={v / tot:.3f}" for n, v in zip(
                 ("refill", "march", "shade_load", "shade_math", "shade_acc"), list(tl.values())[:5]))
             + f"; wave-lifetime cycles/wave {list(tl.values())[5] / max(list(tl.values())[6], 1):.0f}"
-            + f" over {list(tl.values())[6]} waves")
+            + f" over {list(tl.values())[6]} waves; mean tail (queue empty -> wave done) "
+            + f"{list(tl.values())[7] / max(list(tl.values())[6], 1):.0f} cycles")
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

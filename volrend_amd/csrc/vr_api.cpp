@@ -484,7 +484,7 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     t->max_depth = max_depth;
     hipError_t e = hipGetDevice(&t->device);
     // Stage the reference arrays on the device (unless they already are there),
-    // re-layout into nodes/leaves, build the restart grid, drop the staging copy.
+    // re-layout into nodes/leaves, build the lookup structure, drop the staging copy.
     int32_t* d_child = nullptr;
     uint16_t* d_data = nullptr;
     const int32_t* src_child = d->child;

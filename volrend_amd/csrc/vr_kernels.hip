@@ -42,10 +42,6 @@ constexpr int kWave = 64;
 #ifndef VR_SH9_WAVES
 #define VR_SH9_WAVES 6  // (7 fits the LDS but needs 72 VGPRs: scratch)
 #endif
-#ifndef VR_PAIRED_CHANNELS
-#define VR_PAIRED_CHANNELS 0  // 1: strict model, channels 0/1 accumulate in a register pair (v_pk_add_f32):
-                               // -15 VALU per SH16 round but +5 live registers = scratch at 96 VGPRs
-#endif
 #ifndef VR_PACKED_EXP
 #define VR_PACKED_EXP 1       // the sigmoids of channels 0/1 share packed mul / fma / add instructions
 #endif
@@ -487,48 +483,6 @@ __device__ __forceinline__ void add_group(const char* row, GET&& get, float* acc
     }
 }
 
-// STRICT model, channels 0 and 1 side by side: their group sums are the same chain of roundings
-// on different coefficients, so the two running sums live in one register pair and every
-// "+ product" of the pair is ONE v_pk_add_f32 (the products stay v_fma_mix_f32, one per
-// coefficient).  5 instead of 6 VALU instructions per basis function; bit-identical to
-// add_group<0, ...> (each component of a packed add rounds like the scalar add).
-template <int BASIS, int LO, int HI, typename GET>
-__device__ __forceinline__ void add_group_paired(const char* row, GET&& get, float2v& a01, float& a2) {
-    float b[VR_MAX_BASIS];
-#pragma unroll
-    for (int i = LO; i <= HI; ++i) b[i] = get(i);
-    GroupWin<BASIS, 0, LO, HI> w0;
-    GroupWin<BASIS, 1, LO, HI> w1;
-    w0.load(row);
-    w1.load(row);
-    // g = b[LO]*v[LO] + b[LO+1]*v[LO+1], then + b[I]*v[I] for I = LO+2 .. HI  (DotGroup::run)
-    float2v g = (float2v){coef_mul<0 * BASIS + LO>(b[LO], w0), coef_mul<1 * BASIS + LO>(b[LO], w1)} +
-                (float2v){coef_mul<0 * BASIS + LO + 1>(b[LO + 1], w0),
-                          coef_mul<1 * BASIS + LO + 1>(b[LO + 1], w1)};
-    __builtin_amdgcn_sched_barrier(0);
-    auto step = [&](auto I) {
-        constexpr int i = decltype(I)::value;
-        g = (float2v){coef_mul<0 * BASIS + i>(b[i], w0), coef_mul<1 * BASIS + i>(b[i], w1)} + g;
-        // (the products are independent of the chain: unfenced, the scheduler computes them all
-        // up front and the register allocator pays for it with scratch)
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    if constexpr (LO + 2 <= HI) step(std::integral_constant<int, LO + 2>{});
-    if constexpr (LO + 3 <= HI) step(std::integral_constant<int, LO + 3>{});
-    if constexpr (LO + 4 <= HI) step(std::integral_constant<int, LO + 4>{});
-    if constexpr (LO + 5 <= HI) step(std::integral_constant<int, LO + 5>{});
-    if constexpr (LO + 6 <= HI) step(std::integral_constant<int, LO + 6>{});
-    if constexpr (LO + 7 <= HI) step(std::integral_constant<int, LO + 7>{});
-    if constexpr (LO + 8 <= HI) step(std::integral_constant<int, LO + 8>{});
-    static_assert(HI - LO <= 8, "groups of at most nine basis functions");
-    a01 = a01 + g;
-    {
-        GroupWin<BASIS, 2, LO, HI> w2;
-        w2.load(row);
-        a2 += DotGroup<0, 2 * BASIS, LO, HI>::run(b, w2);
-    }
-}
-
 template <int FMA, int BASIS, typename GET>
 __device__ __forceinline__ void channel_sums(const char* row, GET&& get, float* acc) {
     static_assert(BASIS > 1, "SH / SG / ASG sizes only");
@@ -544,20 +498,10 @@ __device__ __forceinline__ void channel_sums(const char* row, GET&& get, float* 
         acc[1] = coef_mul<1 * BASIS>(b0, w1);
         acc[2] = coef_mul<2 * BASIS>(b0, w2);
     }
-    if constexpr (FMA == 0 && VR_PAIRED_CHANNELS) {
-        float2v a01 = {acc[0], acc[1]};
-        if constexpr (BASIS == 25) add_group_paired<BASIS, 16, 24>(row, get, a01, acc[2]);
-        if constexpr (BASIS >= 16) add_group_paired<BASIS, 9, 15>(row, get, a01, acc[2]);
-        if constexpr (BASIS >= 9) add_group_paired<BASIS, 4, 8>(row, get, a01, acc[2]);
-        if constexpr (BASIS >= 4) add_group_paired<BASIS, 1, 3>(row, get, a01, acc[2]);
-        acc[0] = a01.x;
-        acc[1] = a01.y;
-    } else {
-        if constexpr (BASIS == 25) add_group<FMA, BASIS, 16, 24>(row, get, acc);
-        if constexpr (BASIS >= 16) add_group<FMA, BASIS, 9, 15>(row, get, acc);
-        if constexpr (BASIS >= 9) add_group<FMA, BASIS, 4, 8>(row, get, acc);
-        if constexpr (BASIS >= 4) add_group<FMA, BASIS, 1, 3>(row, get, acc);
-    }
+    if constexpr (BASIS == 25) add_group<FMA, BASIS, 16, 24>(row, get, acc);
+    if constexpr (BASIS >= 16) add_group<FMA, BASIS, 9, 15>(row, get, acc);
+    if constexpr (BASIS >= 9) add_group<FMA, BASIS, 4, 8>(row, get, acc);
+    if constexpr (BASIS >= 4) add_group<FMA, BASIS, 1, 3>(row, get, acc);
 }
 
 __device__ __forceinline__ uint32_t quant8(float v) {
@@ -999,7 +943,8 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
 
 #if VR_TIMELINE
     unsigned long long tl_refill = 0, tl_march = 0, tl_shade_load = 0, tl_shade_math = 0,
-                       tl_shade_acc = 0, tl_total0 = __builtin_readcyclecounter(), tl_mark = 0;
+                       tl_shade_acc = 0, tl_total0 = __builtin_readcyclecounter(), tl_mark = 0,
+                       tl_drained = 0;  // when this wave found the ray queue empty
 #define TL_MARK() (tl_mark = __builtin_readcyclecounter())
 #define TL_ADD(v) do { const unsigned long long n_ = __builtin_readcyclecounter(); \
                        (v) += n_ - tl_mark; tl_mark = n_; } while (0)
@@ -1208,6 +1153,9 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 hi = __builtin_amdgcn_readfirstlane(hi);
                 if (hi == lo) {
                     exhausted = true;
+#if VR_TIMELINE
+                    tl_drained = __builtin_readcyclecounter();
+#endif
                 } else {
                     chunk_next = lo;
                     chunk_end = hi;
@@ -1370,6 +1318,8 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         atomicAdd(&p.sched_stats[4], tl_shade_acc);
         atomicAdd(&p.sched_stats[5], (unsigned long long)__builtin_readcyclecounter() - tl_total0);
         atomicAdd(&p.sched_stats[6], 1ull);
+        // the wave's tail: from the moment the queue was empty to its last retired ray
+        atomicAdd(&p.sched_stats[7], (unsigned long long)__builtin_readcyclecounter() - tl_drained);
     }
 #endif
     if (COUNT && p.sched_stats && lane == 0) {
