@@ -52,6 +52,8 @@ class TileShardRenderer {
     void sync();
 
    private:
+    void init(const N3Tree& tree, const TileShardConfig& cfg);
+    void release();
     int n_, width_, height_, tile_w_, tile_h_, max_batch_;
     bool share_, rccl_self_;
     int64_t compact_bytes_ = 0;  // one rank's share of one frame

@@ -37,6 +37,15 @@ TileShardRenderer::TileShardRenderer(const N3Tree& tree, int width, int height,
       max_batch_(cfg.max_batch < 1 ? 1 : (cfg.max_batch > VR_MAX_BATCH ? VR_MAX_BATCH : cfg.max_batch)),
       share_(cfg.share_device && n_ > 1),
       rccl_self_(n_ == 1) {
+    try {
+        init(tree, cfg);
+    } catch (...) {
+        release();  // a constructor that throws gets no destructor call
+        throw;
+    }
+}
+
+void TileShardRenderer::init(const N3Tree& tree, const TileShardConfig& cfg) {
     if (!tree.device) throw std::runtime_error("TileShardRenderer: the tree is not on a device");
     int n_dev = 0;
     hip_ok(hipGetDeviceCount(&n_dev), "hipGetDeviceCount");
@@ -109,30 +118,46 @@ TileShardRenderer::TileShardRenderer(const N3Tree& tree, int width, int height,
     hip_ok(hipSetDevice(prev), "hipSetDevice");
 }
 
-TileShardRenderer::~TileShardRenderer() {
+TileShardRenderer::~TileShardRenderer() { release(); }
+
+void TileShardRenderer::release() {
     int prev = 0;
     (void)hipGetDevice(&prev);
-    for (int r = 0; r < n_; ++r) {
+    const int n = (int)device_.size();  // (a failed construction may have got this far only)
+    for (int r = 0; r < n; ++r) {
         (void)hipSetDevice(device_[r]);
         (void)hipDeviceSynchronize();
     }
     for (void* c : comm_) (void)ncclCommDestroy(nc(c));
-    for (int r = 0; r < n_; ++r) {
+    comm_.clear();
+    auto at = [](const auto& v, int r) { return r < (int)v.size() ? v[r] : nullptr; };
+    for (int r = 0; r < n; ++r) {
         (void)hipSetDevice(device_[r]);
         for (int s = 0; s < 2; ++s) {
-            if (compact_[s][r]) (void)hipFree(compact_[s][r]);
-            if (rendered_[s][r]) (void)hipEventDestroy(he(rendered_[s][r]));
-            if (released_[s][r]) (void)hipEventDestroy(he(released_[s][r]));
+            if (at(compact_[s], r)) (void)hipFree(compact_[s][r]);
+            if (at(rendered_[s], r)) (void)hipEventDestroy(he(rendered_[s][r]));
+            if (at(released_[s], r)) (void)hipEventDestroy(he(released_[s][r]));
         }
-        if (render_stream_[r]) (void)hipStreamDestroy(hs(render_stream_[r]));
-        if (comm_stream_[r]) (void)hipStreamDestroy(hs(comm_stream_[r]));
-        if (owns_tree_[r] && tree_[r]) (void)vr_tree_free(tree_[r]);
+        if (at(render_stream_, r)) (void)hipStreamDestroy(hs(render_stream_[r]));
+        if (at(comm_stream_, r)) (void)hipStreamDestroy(hs(comm_stream_[r]));
+        if (r < (int)owns_tree_.size() && owns_tree_[r] && tree_[r]) (void)vr_tree_free(tree_[r]);
     }
-    (void)hipSetDevice(device_[0]);
+    for (int s = 0; s < 2; ++s) {
+        compact_[s].clear();
+        rendered_[s].clear();
+        released_[s].clear();
+    }
+    render_stream_.clear();
+    comm_stream_.clear();
+    tree_.clear();
+    owns_tree_.clear();
+    if (n > 0) (void)hipSetDevice(device_[0]);
     for (int s = 0; s < 2; ++s) {
         if (gather_[s]) (void)hipFree(gather_[s]);
         if (frames_[s]) (void)hipFree(frames_[s]);
+        gather_[s] = frames_[s] = nullptr;
     }
+    device_.clear();
     (void)hipSetDevice(prev);
 }
 
