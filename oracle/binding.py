@@ -209,6 +209,27 @@ def render(th: TreeHandle, cam: OrCamera, opt: OrOptions, fp_mode=FP_STRICT, reg
     return rgba, accum, cnt.as_dict()
 
 
+def render_maps(th: TreeHandle, cam: OrCamera, opt: OrOptions, fp_mode=FP_STRICT, nthreads=None):
+    """Per-pixel work of one frame: (samples uint32 [H,W], hit samples uint32 [H,W], counters)."""
+    W, H = cam.width, cam.height
+    samples = np.zeros((H, W), dtype=np.uint32)
+    hits = np.zeros((H, W), dtype=np.uint32)
+    cnt = OrCounters()
+    L = lib()
+    L.or_render_maps.restype = C.c_int
+    L.or_render_maps.argtypes = [C.POINTER(OrTree), C.POINTER(OrCamera), C.POINTER(OrOptions),
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.POINTER(OrCounters), C.c_int, C.c_void_p, C.c_void_p]
+    rc = L.or_render_maps(C.byref(th.struct), C.byref(cam), C.byref(opt), fp_mode, 1, 0, 0, W, H,
+                          None, None, None, None, None, C.byref(cnt),
+                          int(nthreads or os.cpu_count() or 1), samples.ctypes.data,
+                          hits.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"or_render_maps failed rc={rc}")
+    return samples, hits, cnt.as_dict()
+
+
 def ref_render(th: TreeHandle, cam: OrCamera, opt: OrOptions, region=None, offscreen=True,
                rgba_init=None, depth_init=None, libm_expf=False, nthreads=None):
     """Run the reference's render_kernel on the host. -> rgba uint8 [H,W,4]."""

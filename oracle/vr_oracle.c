@@ -47,6 +47,8 @@ typedef struct Job {
     const uint8_t* rgba_init;
     const float* depth_init;
     const float* probe_coeffs;
+    uint32_t* samples_map; /* optional per-pixel sample / hit-sample counts (or_render_maps) */
+    uint32_t* hits_map;
     long next_item; /* atomic work dispenser */
     pthread_mutex_t mu;
     OrCounters total;
@@ -76,6 +78,7 @@ static void* worker(void* arg) {
         const int xs = j->x0 + (int)(item % per_row) * chunk;
         const int xe = xs + chunk < j->x0 + j->w ? xs + chunk : j->x0 + j->w;
         for (int x = xs; x < xe; ++x) {
+            const uint64_t s0 = local.samples, h0 = local.hit_samples;
             if (j->fp_mode == OR_FP_FMA)
                 render_pixel_fma(j->tree, j->cam, j->opt, j->offscreen, x, y, j->rgba, j->accum,
                                  j->rgba_init, j->depth_init, j->probe_coeffs, &local);
@@ -83,6 +86,10 @@ static void* worker(void* arg) {
                 render_pixel_strict(j->tree, j->cam, j->opt, j->offscreen, x, y, j->rgba,
                                     j->accum, j->rgba_init, j->depth_init, j->probe_coeffs,
                                     &local);
+            if (j->samples_map)
+                j->samples_map[(size_t)y * j->cam->width + x] = (uint32_t)(local.samples - s0);
+            if (j->hits_map)
+                j->hits_map[(size_t)y * j->cam->width + x] = (uint32_t)(local.hit_samples - h0);
         }
     }
     pthread_mutex_lock(&j->mu);
@@ -95,6 +102,14 @@ int or_render(const OrTree* tree, const OrCamera* cam, const OrOptions* opt, int
               int offscreen, int x0, int y0, int w, int h, uint8_t* rgba, float* accum,
               const uint8_t* rgba_init, const float* depth_init, const float* probe_coeffs,
               OrCounters* counters, int nthreads) {
+    return or_render_maps(tree, cam, opt, fp_mode, offscreen, x0, y0, w, h, rgba, accum, rgba_init,
+                          depth_init, probe_coeffs, counters, nthreads, NULL, NULL);
+}
+
+int or_render_maps(const OrTree* tree, const OrCamera* cam, const OrOptions* opt, int fp_mode,
+                   int offscreen, int x0, int y0, int w, int h, uint8_t* rgba, float* accum,
+                   const uint8_t* rgba_init, const float* depth_init, const float* probe_coeffs,
+                   OrCounters* counters, int nthreads, uint32_t* samples_map, uint32_t* hits_map) {
     if (!tree || !cam || !opt) return 1;
     if (x0 < 0 || y0 < 0 || w < 0 || h < 0 || x0 + w > cam->width || y0 + h > cam->height)
         return 2;
@@ -115,6 +130,8 @@ int or_render(const OrTree* tree, const OrCamera* cam, const OrOptions* opt, int
     job.rgba_init = rgba_init;
     job.depth_init = depth_init;
     job.probe_coeffs = probe_coeffs;
+    job.samples_map = samples_map;
+    job.hits_map = hits_map;
     pthread_mutex_init(&job.mu, NULL);
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;

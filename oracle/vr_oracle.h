@@ -108,6 +108,15 @@ int or_render(const OrTree* tree, const OrCamera* cam, const OrOptions* opt,
               const float* depth_init, const float* probe_coeffs,
               OrCounters* counters, int nthreads);
 
+/* or_render + per-pixel work maps (full-frame uint32 arrays, either may be NULL): the number of
+ * samples / of samples above sigma_thresh each pixel's ray took -- the per-ray cost the
+ * scheduling studies need (tools/ray_length_study.py). */
+int or_render_maps(const OrTree* tree, const OrCamera* cam, const OrOptions* opt,
+                   int fp_mode, int offscreen, int x0, int y0, int w, int h,
+                   uint8_t* rgba, float* accum, const uint8_t* rgba_init,
+                   const float* depth_init, const float* probe_coeffs,
+                   OrCounters* counters, int nthreads, uint32_t* samples_map, uint32_t* hits_map);
+
 /* retrieve_cursor_lumisphere_kernel, volrend.cu:175-191: out[data_dim-1] */
 void or_probe_coeffs(const OrTree* tree, const OrOptions* opt, float* out);
 
