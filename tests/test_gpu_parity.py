@@ -61,7 +61,8 @@ def test_sh_bit_exact(torch_cuda, basis_dim, fp_mode):
 
 
 @pytest.mark.parametrize("fp_mode", [0, 1])
-@pytest.mark.parametrize("fmt,basis_dim", [("RGBA", 0), ("SG", 9), ("SG", 25), ("ASG", 4), ("SG", 7)])
+@pytest.mark.parametrize("fmt,basis_dim", [("RGBA", 0), ("SG", 9), ("SG", 25), ("ASG", 4), ("SG", 7),
+                                           ("SG", 23), ("ASG", 25)])  # 23, 25: records beyond one line (head + tail)
 def test_other_formats_bit_exact(torch_cuda, fmt, basis_dim, fp_mode):
     tree = common.small_scene(depth=5, basis_dim=basis_dim, fmt=fmt, seed=31)
     tr, w, h, f = common.camera_for(pose_idx=5, size=80)

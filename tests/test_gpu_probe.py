@@ -144,7 +144,7 @@ def test_probe_batch_and_tile_shards(torch_cuda, fp_mode):
     t.free_device()
 
 
-@pytest.mark.parametrize("fmt,basis_dim", [("SH", 16), ("SH", 9), ("RGBA", 0), ("SG", 4)])
+@pytest.mark.parametrize("fmt,basis_dim", [("SH", 16), ("SH", 9), ("SH", 25), ("RGBA", 0), ("SG", 4)])
 def test_probe_coeffs_match_oracle(torch_cuda, fmt, basis_dim):
     """vr_probe_coeffs == retrieve_cursor_lumisphere_kernel (volrend.cu:175-191): the
     data_dim - 1 values of the leaf that holds opt.probe, as floats -- compared with the
