@@ -159,3 +159,31 @@ def test_bench_reports_traffic_only_for_the_sources_it_was_measured_on(tmp_path)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from measure_traffic import kernel_source_hash
     assert kernel_source_hash() == kernel_source_hash() and len(kernel_source_hash()) == 64
+
+
+def test_measure_traffic_parses_rocprofv3_csvs(tmp_path):
+    """tools/measure_traffic.collect(): counter values are summed over the XCD instances of a
+    dispatch and averaged over the dispatches of the kernel flavour asked for; durations come
+    from the kernel trace of the same pass."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import measure_traffic as mt
+    k = "void vr::(anonymous namespace)::render_kernel<0, 16, 0>(vr::KParams)"
+    other = "void vr::(anonymous namespace)::render_kernel<0, 16, 1>(vr::KParams)"
+    d = tmp_path / "box" / "123"
+    d.mkdir(parents=True)
+    rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
+    for disp, base in ((7, 100.0), (9, 300.0)):
+        for xcd in range(8):                       # one row per XCD instance
+            rows.append(f'{disp},"{k}",TCC_EA0_RDREQ_128B_sum,{base}')
+            rows.append(f'{disp},"{k}",TCC_EA0_RDREQ_sum,{base}')
+    rows.append(f'11,"{other}",TCC_EA0_RDREQ_128B_sum,99999')   # instrumented flavour: ignored
+    (d / "rdsize_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    (d / "rdsize_kernel_trace.csv").write_text(
+        "Kernel_Name,Start_Timestamp,End_Timestamp\n"
+        f'"{k}",1000,3000\n"{k}",5000,9000\n"{other}",0,100000\n')
+    vals, dur = mt.collect(str(tmp_path), "rdsize", "render_kernel<0, 16, 0>")
+    assert sorted(vals["TCC_EA0_RDREQ_128B_sum"]) == [800.0, 2400.0]
+    assert sorted(dur) == [2000.0, 4000.0]
+    # the group table never offers the counters that abort rocprofv3 on this pool
+    assert not any(c.startswith(("TA_", "TD_")) for g in mt.GROUPS.values() for c in g.split())
