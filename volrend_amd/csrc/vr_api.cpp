@@ -10,6 +10,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <thread>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -451,10 +452,53 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
         HIP_TRY(hipMemcpy(staged.data(), d->child, child_sz, hipMemcpyDeviceToHost));
         host_child = staged.data();
     }
+    // The big host-to-device copies (and the codebook decode of a quantised file) run on a
+    // helper thread while this one walks the tree on the host (topology check, node numbering):
+    // the walks only read the child array, and hide completely behind the copies.
+    // (a malformed tree is reported as such even where no device exists: no HIP error before that)
+    int device = 0;
+    const hipError_t e_dev = hipGetDevice(&device);
+    int32_t* d_child = nullptr;
+    uint16_t* d_data = nullptr;
+    hipError_t e_copy = e_dev;
+    std::thread copier([&] {
+        if (e_dev != hipSuccess) return;
+        hipError_t e = hipSetDevice(device);
+        if (d->memory != 1) {
+            if (e == hipSuccess) e = hipMalloc((void**)&d_child, child_sz);
+            if (e == hipSuccess) e = hipMemcpy(d_child, d->child, child_sz, hipMemcpyHostToDevice);
+        }
+        if (q) {  // quantised file: only the codebook arrays cross PCIe, the decode runs on the device
+            if (e == hipSuccess) e = hipMalloc((void**)&d_data, data_sz);
+            if (e == hipSuccess) e = decode_quant_on_device(d, q, n_slots, d_data);
+        } else if (d->memory != 1) {
+            if (e == hipSuccess) e = hipMalloc((void**)&d_data, data_sz);
+            if (e == hipSuccess) e = hipMemcpy(d_data, d->data, data_sz, hipMemcpyHostToDevice);
+        }
+        e_copy = e;
+    });
+    struct Joiner {  // every exit below waits for the copies and drops the staging buffers
+        std::thread& th;
+        int32_t*& c;
+        uint16_t*& dd;
+        bool keep = false;
+        ~Joiner() {
+            if (th.joinable()) th.join();
+            if (!keep) {
+                if (c) (void)hipFree(c);
+                if (dd) (void)hipFree(dd);
+                c = nullptr;
+                dd = nullptr;
+            }
+        }
+    } joiner{copier, d_child, d_data};
+
     char why[256];
     std::vector<uint8_t> level;
     const int max_depth = validate_topology(host_child, d->capacity, N3, level, why, sizeof(why));
     if (max_depth < 0) return fail(VR_ERR_BAD_TREE, "bad tree: %s", why);
+    if (e_dev != hipSuccess)
+        return fail(VR_ERR_HIP, "hipGetDevice failed: %s", hipGetErrorString(e_dev));
     // Lookup structure (N == 2 fast path): leaves must sit within 24 levels (exact integer
     // digits of a binary32 coordinate) and node*8+slot byte offsets must fit 32 bits.
     int G0 = 0, BL = 0;
@@ -482,41 +526,26 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     t->desc.data = nullptr;
     t->desc.extra = nullptr;
     t->max_depth = max_depth;
-    hipError_t e = hipGetDevice(&t->device);
-    // Stage the reference arrays on the device (unless they already are there),
-    // re-layout into nodes/leaves, build the lookup structure, drop the staging copy.
-    int32_t* d_child = nullptr;
-    uint16_t* d_data = nullptr;
-    const int32_t* src_child = d->child;
-    const uint16_t* src_data = d->data;
-    if (d->memory != 1) {
-        if (e == hipSuccess) e = hipMalloc((void**)&d_child, child_sz);
-        if (e == hipSuccess) e = hipMemcpy(d_child, d->child, child_sz, hipMemcpyHostToDevice);
-        src_child = d_child;
-    }
-    if (q) {  // quantised file: only the codebook arrays cross PCIe, the decode runs here
-        if (e == hipSuccess) e = hipMalloc((void**)&d_data, data_sz);
-        if (e == hipSuccess) e = decode_quant_on_device(d, q, n_slots, d_data);
-        src_data = d_data;
-    } else if (d->memory != 1) {
-        if (e == hipSuccess) e = hipMalloc((void**)&d_data, data_sz);
-        if (e == hipSuccess) e = hipMemcpy(d_data, d->data, data_sz, hipMemcpyHostToDevice);
-        src_data = d_data;
-    }
+    t->device = device;
+    // new node numbering (host walk) while the copies are still in flight
+    std::vector<int32_t> brick_roots;
+    const std::vector<int32_t> perm =
+        node_permutation(host_child, d->capacity, N3, G0, BL, level, brick_roots);
+    // the reference arrays are staged on the device now (unless they already were there);
+    // re-layout into nodes/leaves, build the lookup structure, drop the staging copies
+    copier.join();
+    hipError_t e = e_copy;
+    const int32_t* src_child = d->memory != 1 ? d_child : d->child;
+    const uint16_t* src_data = (q || d->memory != 1) ? d_data : d->data;
     t->leaf_stride_h = vr::leaf_stride_halfs(d->data_dim);
     const size_t leaves_sz = n_slots * (size_t)t->leaf_stride_h * sizeof(uint16_t);
     if (e == hipSuccess) e = hipMalloc((void**)&t->nodes, child_sz);
     if (e == hipSuccess) e = hipMalloc((void**)&t->leaves, leaves_sz);
     if (e == hipSuccess) e = alloc_launch_scratch(t);
     int32_t* d_perm = nullptr;
-    std::vector<int32_t> brick_roots;
-    {
-        const std::vector<int32_t> perm =
-            node_permutation(host_child, d->capacity, N3, G0, BL, level, brick_roots);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_perm, perm.size() * sizeof(int32_t));
-        if (e == hipSuccess)
-            e = hipMemcpy(d_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice);
-    }
+    if (e == hipSuccess) e = hipMalloc((void**)&d_perm, perm.size() * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipMemcpy(d_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = vr::launch_relayout(src_child, src_data, d_perm, t->nodes, t->leaves, (int64_t)n_slots,
                                 N3, d->data_dim, t->leaf_stride_h, nullptr);
@@ -543,8 +572,6 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
         if (e == hipSuccess && flag != 0) {
             if (d_roots) (void)hipFree(d_roots);
             if (d_perm) (void)hipFree(d_perm);
-            if (d_child) (void)hipFree(d_child);
-            if (d_data) (void)hipFree(d_data);
             vr_tree_free(t);
             return fail(VR_ERR_BAD_TREE, "lookup structure build failed (flag %u)", flag);
         }
@@ -560,8 +587,6 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     if (d_roots) (void)hipFree(d_roots);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (d_perm) (void)hipFree(d_perm);
-    if (d_child) (void)hipFree(d_child);
-    if (d_data) (void)hipFree(d_data);
     if (e == hipSuccess && d->extra && d->extra_count) {
         const size_t esz = (size_t)d->extra_count * sizeof(float);
         const hipMemcpyKind kind =
