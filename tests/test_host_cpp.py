@@ -122,6 +122,45 @@ def test_png_writer(exe, tmp_path):
     assert np.array_equal(im[..., 2], (xs ^ ys) % 256) and (im[..., 3] == 255).all()
 
 
+@pytest.mark.parametrize("w,h", [(37, 21), (800, 800), (1, 1), (5000, 4)])
+def test_png_is_stored_not_deflated(exe, tmp_path, w, h):
+    """The reference asks libpng for level 0 / no filter (src/imwrite.cpp:29-31): the IDAT is a
+    zlib stream of STORED blocks.  Chunk CRCs, block structure, Adler-32 and the exact file size."""
+    import struct
+    import zlib
+    p = str(tmp_path / "s.png")
+    run(exe, "png", p, str(w), str(h))
+    b = open(p, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    at, chunks = 8, []
+    while at < len(b):
+        n, typ = struct.unpack(">I4s", b[at:at + 8])
+        body = b[at + 8:at + 8 + n]
+        assert struct.unpack(">I", b[at + 8 + n:at + 12 + n])[0] == zlib.crc32(typ + body)
+        chunks.append((typ, body))
+        at += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (w, h, 8, 6, 0, 0, 0)
+    z = chunks[1][1]
+    raw_len = (w * 4 + 1) * h
+    assert z[:2] == b"\x78\x01"
+    at, got = 2, bytearray()
+    while True:
+        final, n, nn = z[at], *struct.unpack("<HH", z[at + 1:at + 5])
+        assert final in (0, 1) and n == (~nn & 0xFFFF)      # BTYPE 00: stored
+        got += z[at + 5:at + 5 + n]
+        at += 5 + n
+        if final:
+            break
+        assert n == 65535
+    assert len(got) == raw_len and struct.unpack(">I", z[at:at + 4])[0] == zlib.adler32(bytes(got))
+    assert at + 4 == len(z) and zlib.decompress(z) == bytes(got)
+    n_blocks = (raw_len + 65534) // 65535
+    assert len(b) == 8 + 25 + 12 + (2 + 5 * n_blocks + raw_len + 4) + 12
+    rows = np.frombuffer(bytes(got), np.uint8).reshape(h, w * 4 + 1)
+    assert (rows[:, 0] == 0).all()                           # filter type none on every row
+
+
 def test_option_parser(exe):
     out = run(exe, "opts", "tree.npz", "pose/0000.txt", "-w", "400", "--height=300", "--fx", "555.5",
               "-o", "out", "-r", "-s", "1e-3", "--bg", "0.5", "pose/0001.txt", "--unknown", "-e",

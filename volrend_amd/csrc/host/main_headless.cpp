@@ -313,17 +313,26 @@ int main(int argc, char* argv[]) {
                sc.tile_rows < 8 ? 8 : sc.tile_rows / 8 * 8, shard->transport().c_str());
         HIP_OK(hipSetDevice(shard->root_device()));
     }
-    std::vector<void*> images(batch, nullptr);
+    // Device frames: two sets of `batch` contiguous frames -- launch k renders into set k % 2
+    // while the read-back of launch k - 1 drains the other one (the tile shard brings its own).
+    uint8_t* image_sets[2] = {nullptr, nullptr};
     if (!shard)
-        for (int i = 0; i < batch; ++i) HIP_OK(hipMalloc(&images[i], frame_bytes));
+        for (auto& is : image_sets) HIP_OK(hipMalloc((void**)&is, frame_bytes * batch));
     uint8_t* host_sets[2] = {nullptr, nullptr};  // pinned, one per in-flight batch
     std::unique_ptr<EncodePool> pool;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t rendered[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
     if (!out_dir.empty()) {
         make_dirs(out_dir);
         for (auto& hs : host_sets) HIP_OK(hipHostMalloc((void**)&hs, frame_bytes * batch));
         unsigned nt = std::thread::hardware_concurrency();
-        nt = nt == 0 ? 4 : (nt > 16 ? 16 : nt);
+        nt = nt == 0 ? 4 : (nt > 32 ? 32 : nt);
         pool.reset(new EncodePool(nt));
+        HIP_OK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_OK(hipEventCreateWithFlags(&rendered[i], hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+        }
     }
     hipStream_t stream;
     if (shard) stream = static_cast<hipStream_t>(shard->out_stream());
@@ -332,10 +341,26 @@ int main(int argc, char* argv[]) {
     HIP_OK(hipEventCreate(&start));
     HIP_OK(hipEventCreate(&stop));
 
+    // Frame egress of launch `seq` (frames [first, first + n)): called one launch late, so the
+    // host waits for the copies of launch k - 1 while the GPU renders launch k.
+    auto submit_encodes = [&](int set, size_t first, int n) {
+        HIP_OK(hipEventSynchronize(copied[set]));
+        for (int i = 0; i < n; ++i) {
+            const std::string fpath = out_dir + "/" + basenames[first + i] + ".png";
+            const uint8_t* src = host_sets[set] + frame_bytes * i;
+            pool->submit(set, [fpath, src, width, height] {
+                internal::write_png_file(fpath, src, width, height);
+            });
+        }
+    };
+
     HIP_OK(hipEventRecord(start, stream));
     int seq = 0;
+    size_t prev_first = 0;
+    int prev_n = 0;
     for (size_t first = 0; first < trans.size(); first += batch, ++seq) {
         const int n = (int)std::min<size_t>(batch, trans.size() - first);
+        const int set = seq & 1;
         std::vector<VrCamera> cams((size_t)n);
         std::vector<VrFrame> frames((size_t)n);
         for (int i = 0; i < n; ++i) {
@@ -346,10 +371,14 @@ int main(int argc, char* argv[]) {
             cams[i].fx = fx;
             cams[i].fy = fy;
             vr_default_frame(&frames[i]);
-            frames[i].rgba = images[i];
+            frames[i].rgba = shard ? nullptr : image_sets[set] + frame_bytes * i;
             frames[i].offscreen = 1;
             frames[i].fp_mode = fp_mode;
         }
+        // set `set` of the device frames was read back by launch seq - 2: that copy must be done
+        // before this launch overwrites them (device-side wait, the host does not block)
+        if (copy_stream && seq >= 2) HIP_OK(hipStreamWaitEvent(stream, copied[set], 0));
+        const uint8_t* dev_frames = nullptr;
         if (shard) {
             try {
                 shard->render(seq, cams.data(), n, copt, fp_mode);
@@ -357,36 +386,31 @@ int main(int argc, char* argv[]) {
                 fprintf(stderr, "ERROR: %s\n", e.what());
                 return 1;
             }
-            for (int i = 0; i < n; ++i) images[i] = shard->frames(seq & 1) + frame_bytes * i;
-        } else if (vr_render_batch(tree.device, n, cams.data(), &copt, frames.data(), stream) !=
-                   VR_OK) {
-            fprintf(stderr, "ERROR: %s\n", vr_last_error());
-            return 1;
-        }
-        if (!out_dir.empty()) {
-            const int set = seq & 1;
-            pool->wait(set);  // the encoders are done with this buffer set
-            for (int i = 0; i < n; ++i) {
-                if (vr_read_back(host_sets[set] + frame_bytes * i, images[i], 0, width, height,
-                                 stream) != VR_OK) {
-                    fprintf(stderr, "ERROR: %s\n", vr_last_error());
-                    return 1;
-                }
-            }
-            if (vr_stream_sync(stream) != VR_OK) {
+            dev_frames = shard->frames(set);
+        } else {
+            if (vr_render_batch(tree.device, n, cams.data(), &copt, frames.data(), stream) != VR_OK) {
                 fprintf(stderr, "ERROR: %s\n", vr_last_error());
                 return 1;
             }
-            for (int i = 0; i < n; ++i) {
-                const std::string fpath = out_dir + "/" + basenames[first + i] + ".png";
-                const uint8_t* src = host_sets[set] + frame_bytes * i;
-                pool->submit(set, [fpath, src, width, height] {
-                    internal::write_png_file(fpath, src, width, height);
-                });
+            dev_frames = image_sets[set];
+        }
+        if (!out_dir.empty()) {
+            HIP_OK(hipEventRecord(rendered[set], stream));
+            pool->wait(set);  // the encoders (launch seq - 2) are done with this host buffer set
+            HIP_OK(hipStreamWaitEvent(copy_stream, rendered[set], 0));
+            // the n frames of a launch are contiguous: one copy
+            if (vr_read_back(host_sets[set], dev_frames, 0, width, height * n, copy_stream) != VR_OK) {
+                fprintf(stderr, "ERROR: %s\n", vr_last_error());
+                return 1;
             }
+            HIP_OK(hipEventRecord(copied[set], copy_stream));
+            if (prev_n > 0) submit_encodes(set ^ 1, prev_first, prev_n);
+            prev_first = first;
+            prev_n = n;
         }
     }
     if (pool) {
+        if (prev_n > 0) submit_encodes((seq - 1) & 1, prev_first, prev_n);
         pool->wait(0);
         pool->wait(1);
     }
@@ -404,8 +428,13 @@ int main(int argc, char* argv[]) {
     pool.reset();
     for (auto& hs : host_sets)
         if (hs) HIP_OK(hipHostFree(hs));
+    for (int i = 0; i < 2; ++i) {
+        if (rendered[i]) HIP_OK(hipEventDestroy(rendered[i]));
+        if (copied[i]) HIP_OK(hipEventDestroy(copied[i]));
+    }
+    if (copy_stream) HIP_OK(hipStreamDestroy(copy_stream));
     if (!shard) {
-        for (void* p : images) HIP_OK(hipFree(p));
+        for (uint8_t* p : image_sets) HIP_OK(hipFree(p));
         HIP_OK(hipStreamDestroy(stream));
     }
     shard.reset();

@@ -774,7 +774,7 @@ int vr_set_tuning(const char* key, int value) {
     Tuning& tn = tuning();
     if (!strcmp(key, "march_max")) tn.march_max = value < 1 ? 1 : value;
     else if (!strcmp(key, "refill_min")) tn.refill_min = value < 1 ? 1 : (value > 64 ? 64 : value);
-    else if (!strcmp(key, "waves_per_cu")) tn.waves_per_cu = value < 0 ? 0 : (value > 32 ? 32 : value);
+    else if (!strcmp(key, "waves_per_cu")) tn.waves_per_cu = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "shade_min")) tn.shade_min = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "frame_group")) tn.frame_group = value < 0 ? 0 : value;
     else if (!strcmp(key, "super_block")) tn.super_block = value < 1 ? 1 : (value > 64 ? 64 : value);

@@ -1182,11 +1182,13 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     ray.tmax = u2f(ray_word(rs, 10));
                     ray.delta_scale = u2f(ray_word(rs, 11));
                     ray_id = r;
+#if VR_ABLATE != 6
                     if (HAS_BASIS) {
 #pragma unroll
                         for (int i = 0; i < NB; ++i)
                             mybasis[i] = u2f(ray_word(rs, kRayWords + i));
                     }
+#endif
                 }
             }
             if (done)
@@ -1269,7 +1271,11 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     if (COUNT && p.render_depth)  // (depth launches take the FULL flavour)
                         ray.out[0] = P::madd(weight, ray.t, ray.out[0]);
                     else
+#if VR_ABLATE == 6   // timing experiment only: march without any colour work
+                        ray.out[1] += weight;
+#else
                         push = true;
+#endif
                     ray.light *= att;
                     stop = ray.light < p.stop_thresh;
                 }
