@@ -145,8 +145,34 @@ def committed_traffic(config: str, fp: str, profiles_dir: str | None = None, hav
             continue
         return (tj["read_bytes_per_frame"] + tj.get("write_bytes_per_frame", 0.0),
                 f"{rel}: rocprofv3 --pmc passes at {tj['frames_per_launch']} frames per launch, "
-                f"TCC_EA0_RDREQ_128B*128 + _64B*64 + _32B*32 + WRITE_SIZE, kernel source hash verified")
-    return None, reason
+                f"TCC_EA0_RDREQ_128B*128 + _64B*64 + _32B*32 + WRITE_SIZE, kernel source hash verified",
+                int(tj["frames_per_launch"]))
+    return None, reason, None
+
+
+def parity_check(stree, checks, width, height, focal, fp):
+    """BASELINE's metric ends in "PSNR vs ref": frames the TIMED region produced (read back after
+    it, nothing re-rendered) against the CPU oracle -- the checker, pinned bit for bit to the
+    reference's own render_kernel compiled for the host (tests/test_oracle_vs_ref.py).
+    ``checks``: [(step index, 12-float pose, HxWx4 uint8 numpy frame)]."""
+    from oracle import binding as ob
+    th = ob.TreeHandle(stree)
+    opt = ob.default_options()
+    mode = ob.FP_FMA if fp == "fma" else ob.FP_STRICT
+    equal, worst_mse, max_diff, steps = True, 0.0, 0, []
+    for step, tr, got in checks:
+        want, _, _ = ob.render(th, ob.make_camera(tr, width, height, focal), opt, mode,
+                               want_accum=False, nthreads=os.cpu_count() or 1)
+        d = want[..., :3].astype(np.int32) - got[..., :3].astype(np.int32)
+        equal = equal and bool(np.array_equal(want, got))
+        worst_mse = max(worst_mse, float(np.mean(d.astype(np.float64) ** 2)))
+        max_diff = max(max_diff, int(np.abs(d).max()))
+        steps.append(int(step))
+    psnr = None if worst_mse == 0.0 else round(10.0 * np.log10(255.0 ** 2 / worst_mse), 2)
+    return {"frames_checked": len(checks), "steps": steps, "rgba8_equal": equal,
+            "psnr_db": "inf" if psnr is None else psnr, "max_abs_diff_rgb8": max_diff,
+            "against": f"oracle ({fp} mode; == the reference's render_kernel compiled for the host, "
+                       "tests/test_oracle_vs_ref.py), frames taken from the timed region"}
 
 
 def rtfrag_baseline(timeout_s=240):
@@ -195,6 +221,8 @@ def main():
                     help="also copy every frame to pinned host memory inside the timed region "
                          "(the PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the post-run comparison of timed frames with the CPU oracle")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -429,6 +457,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
 
+    # frames of the LAST timed launch stay in their buffer set: first and last of them are
+    # compared with the oracle after the clock has stopped
+    parity_frames = []
+    if rank == 0 and not args.no_parity and not replicas:
+        j_last = n_launch - 1
+        first_last = args.warmup + j_last * B
+        n_last = K - j_last * B
+        for i in sorted({0, n_last - 1}):
+            parity_frames.append((first_last + i, pose_of(first_last + i),
+                                  frame_sets[j_last % 2][i].cpu().numpy()))
+
     if os.environ.get("VR_TIMELINE"):  # profiling build (-DVR_TIMELINE=1): per-phase cycle sums
         tl = tree.sched_stats()
         tot = max(sum(list(tl.values())[:5]), 1)
@@ -467,12 +506,23 @@ def main():
     # counter group per pass), so the bench reports the committed measurement of this config,
     # scaled to this launch size -- but only while the SHA-256 of the kernel sources recorded in
     # it still matches the sources this run was built from; otherwise null, and the reason.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_extrapolated = None, None, None
+    launch_sizes = [min(B, K - j * B) for j in range(n_launch)]
     if world == 1:
-        per_frame, traffic_src = committed_traffic(args.config, args.fp)
+        per_frame, traffic_src, profiled_fpl = committed_traffic(args.config, args.fp)
         if per_frame is not None:
             traffic = int(per_frame * K / n_launch)
+            traffic_extrapolated = any(n != profiled_fpl for n in launch_sizes)
+            if traffic_extrapolated:
+                traffic_src += (f"; EXTRAPOLATED: profiled at {profiled_fpl} frames per launch, this "
+                                f"run launched {launch_sizes[0]} -- bytes per frame scaled to the "
+                                f"launch size, not measured at it")
 
+    tune_kv = dict(kv.split("=") for kv in args.tune.split(",")) if args.tune else {}
+    split = int(tune_kv["split"]) if "split" in tune_kv else int(os.environ.get("VR_SPLIT", "-1"))
+    if split < 0:  # the library's default (vr_api.cpp): SH25 keeps the fused kernel
+        split = int(cfg["basis_dim"] != 25)
+    kernel_name = "render_ms_kernel" if split else "render_kernel"
     if rank == 0:
         # replicas: every rank rendered its own K frames; tile mode: the K frames were shared
         rays_total = W * H * K * (world if replicas else 1)
@@ -499,7 +549,8 @@ def main():
                             f"{info['device_bytes'] / 1e9:.2f} GB in HBM, {W}x{H}, "
                             f"fx=fy={focal}, 200-pose orbit, default RenderOptions",
                 "fp_mode": args.fp,
-                "frames_per_launch": B,
+                "frames_per_launch": launch_sizes[0] if len(set(launch_sizes)) == 1 else launch_sizes,
+                "launches": n_launch,
                 "pcie_inclusive": bool(args.readback),
                 "launch_streams": n_streams,
                 "sharded_frame_matches_single_gpu": shard_ok,
@@ -515,12 +566,19 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "achieved_is": "ALGORITHMIC bytes (SURVEY 8d formula, counted by the instrumented "
+                               "flavour) / launch duration -- mostly served by L2 / Infinity Cache; "
+                               "the HBM-side rate is traffic_gbps",
                 "traffic": traffic,
                 "traffic_unit": "bytes per launch (L2<->fabric reads+writes)",
+                "traffic_extrapolated": traffic_extrapolated,
+                "traffic_gbps": None if traffic is None else round(traffic / kern_mean_s / 1e9, 1),
+                "traffic_frac": None if traffic is None else round(
+                    traffic / kern_mean_s / 1e9 / HBM_PEAK_GBS, 4),
                 "traffic_source": traffic_src,
-                "kernel": f"vr::render_kernel<{args.fp}, {cfg['fmt']}{cfg['basis_dim']}, FAST> "
-                          f"(persistent march/shade, {B} frames per launch; the launch also "
-                          f"runs prepare_launch_kernel + raygen_kernel, ~3 % of its time)",
+                "kernel": f"vr::{kernel_name}<{args.fp}, {cfg['fmt']}{cfg['basis_dim']}> "
+                          f"(persistent march/shade, {launch_sizes[0]} frames per launch; the launch "
+                          f"also runs prepare_launch_kernel + raygen_kernel, ~5 % of its time)",
                 "kernel_ms_mean": round(kern_mean_s * 1e3, 5),
                 "kernel_ms_per_frame": round(kern_total_s / K * 1e3, 5),
                 "alg_bytes_per_launch": int(alg_bytes_per_launch),
@@ -535,6 +593,14 @@ def main():
                     k: int(np.mean([u[k] for u in unique_frames])) for k in unique_frames[0]},
             },
         }
+        if parity_frames:
+            result["parity"] = parity_check(stree, parity_frames, W, H, focal, args.fp)
+            log(f"[bench] parity vs oracle: {result['parity']}")
+        if use_dist:
+            result["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                              "nccl_version": ".".join(map(str, torch.cuda.nccl.version()))
+                              if not share_gpu else None,
+                              "devices": torch.cuda.device_count()}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(stree, transforms, W, H, focal, args.cpu_budget)
             result["cpu_baseline"]["rtfrag"] = rtfrag_baseline()

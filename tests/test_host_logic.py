@@ -145,15 +145,16 @@ def test_bench_reports_traffic_only_for_the_sources_it_was_measured_on(tmp_path)
     (tmp_path / "r07_traffic_C1.json").write_text(json.dumps(rec))
     (tmp_path / "r03_traffic_C1.json").write_text(json.dumps(dict(rec, kernel_source_sha256="old",
                                                                     read_bytes_per_frame=2.0e9)))
-    got, why = bench.committed_traffic("C1", "strict", str(tmp_path), have_hash="abc")
+    got, why, fpl = bench.committed_traffic("C1", "strict", str(tmp_path), have_hash="abc")
     assert got == 1.005e9 and "r07_traffic_C1.json" in why and "verified" in why
-    got, why = bench.committed_traffic("C1", "strict", str(tmp_path), have_hash="old")
+    assert fpl == 64  # the launch shape it was profiled at: another shape is flagged as extrapolated
+    got, why, _ = bench.committed_traffic("C1", "strict", str(tmp_path), have_hash="old")
     assert got == 2.005e9 and "r03_traffic_C1.json" in why      # an older file that still matches
-    got, why = bench.committed_traffic("C1", "strict", str(tmp_path), have_hash="new")
-    assert got is None and "STALE" in why
-    got, why = bench.committed_traffic("C1", "fma", str(tmp_path), have_hash="abc")
+    got, why, fpl = bench.committed_traffic("C1", "strict", str(tmp_path), have_hash="new")
+    assert got is None and "STALE" in why and fpl is None
+    got, why, _ = bench.committed_traffic("C1", "fma", str(tmp_path), have_hash="abc")
     assert got is None
-    got, why = bench.committed_traffic("C9", "strict", str(tmp_path), have_hash="abc")
+    got, why, _ = bench.committed_traffic("C9", "strict", str(tmp_path), have_hash="abc")
     assert got is None and "no profiles" in why
     # the real hash covers the kernel sources and the build flags, and is stable
     sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -85,6 +85,8 @@ def main():
                        "ms_per_frame_min": round(min(ms) / nf, 5),
                        "launch_ms": [round(x, 3) for x in ms], "status": tree.status(),
                        "same_as_first": same}
+                if os.environ.get("VR_TIMELINE"):
+                    rec["sched_stats"] = list(tree.sched_stats().values())
                 print(json.dumps(rec), flush=True)
                 if out:
                     out.write(json.dumps(rec) + "\n")

@@ -43,6 +43,7 @@ struct Tuning {
     int chunk_max = 4096;
     int top_levels = 0;    // lookup structure of trees uploaded from now on (vr_kernels.hip); 0 = auto
     int brick_levels = 3;
+    int split = -1;        // march / shade on separate waves: -1 = where it measures faster, 0 / 1 = forced
 };
 Tuning& tuning() {
     static Tuning tn = [] {
@@ -58,6 +59,7 @@ Tuning& tuning() {
         if (const char* e = getenv("VR_CHUNK_MAX")) x.chunk_max = atoi(e) < 64 ? 64 : (atoi(e) & ~63);
         if (const char* e = getenv("VR_TOP_LEVELS")) x.top_levels = atoi(e);
         if (const char* e = getenv("VR_BRICK_LEVELS")) x.brick_levels = atoi(e);
+        if (const char* e = getenv("VR_SPLIT")) x.split = atoi(e);
         return x;
     }();
     return tn;
@@ -783,6 +785,7 @@ int vr_set_tuning(const char* key, int value) {
     else if (!strcmp(key, "chunk_max")) tn.chunk_max = value < 64 ? 64 : (value & ~63);
     else if (!strcmp(key, "top_levels")) tn.top_levels = value;
     else if (!strcmp(key, "brick_levels")) tn.brick_levels = value;
+    else if (!strcmp(key, "split")) tn.split = value < 0 ? -1 : (value != 0);
     else return fail(VR_ERR_INVALID_ARGUMENT, "unknown tuning key '%s'", key);
     return VR_OK;
 }
@@ -1012,7 +1015,9 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
         }
         HIP_TRY(vr::launch_prepare(k, tbl, hs));
     }
-    HIP_TRY(vr::launch_render(k, f->fp_mode, t->n_cus, tn.waves_per_cu, hs));
+    // SH25 keeps the fused kernel: its shade state does not fit the split kernel's register budget
+    const int split = tn.split >= 0 ? tn.split : (t->desc.basis_dim != 25);
+    HIP_TRY(vr::launch_render(k, f->fp_mode, t->n_cus, tn.waves_per_cu, split, hs));
     HIP_TRY(hipEventRecord(ls.done, hs));
     ls.used = true;
     ls.last_stream = hs;

@@ -106,7 +106,8 @@ struct KParams {
 
 // vr_kernels.hip
 hipError_t launch_prepare(const KParams& p, const FrameTable& tbl, hipStream_t stream);
-hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_override,
+// split != 0: the FAST flavours run march and shade on separate waves (render_ms_kernel)
+hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_override, int split,
                          hipStream_t stream);
 hipError_t launch_assemble(uint8_t* frame, int64_t pitch, const uint8_t* gathered, int width,
                            int height, int tile_w, int tile_h, int world, int n_frames,

@@ -42,6 +42,12 @@ constexpr int kWave = 64;
 #ifndef VR_SH9_WAVES
 #define VR_SH9_WAVES 6  // (7 fits the LDS but needs 72 VGPRs: scratch)
 #endif
+#ifndef VR_MS_SH16_WAVES
+#define VR_MS_SH16_WAVES 8   // split kernel (render_ms_kernel): both roles within 64 VGPRs
+#endif
+#ifndef VR_MS_SH9_WAVES
+#define VR_MS_SH9_WAVES 8
+#endif
 #ifndef VR_PACKED_EXP
 #define VR_PACKED_EXP 1       // the sigmoids of channels 0/1 share packed mul / fma / add instructions
 #endif
@@ -456,14 +462,13 @@ struct GroupWin {
 // (get(i) = basis_fn[i] of the ray that owns the item) right before the three channels use
 // them and are dead afterwards -- the same operations in the same association as
 // channel_dot, with ~12 fewer live registers than gathering the whole basis up front.
-template <int FMA, int BASIS, int LO, int HI, typename GET>
+template <int FMA, int BASIS, int LO, int HI, bool FENCE, typename GET>
 __device__ __forceinline__ void add_group(const char* row, GET&& get, float* acc) {
     float b[VR_MAX_BASIS];
-#if VR_SHADE_SCHED_BARRIER
-    // keeps the scheduler from hoisting the next group's fetches over this group's arithmetic
-    // (lowest register use, but every group then waits for its own LDS round trip)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    // FENCE keeps the scheduler from hoisting the next group's fetches over this group's
+    // arithmetic (lowest register use, but every group then waits for its own LDS round trip):
+    // the shade wave of the split kernel, whose budget is 64 registers and which has time to spare
+    if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = LO; i <= HI; ++i) b[i] = get(i);
     {
@@ -483,7 +488,7 @@ __device__ __forceinline__ void add_group(const char* row, GET&& get, float* acc
     }
 }
 
-template <int FMA, int BASIS, typename GET>
+template <int FMA, int BASIS, bool FENCE = (VR_SHADE_SCHED_BARRIER != 0), typename GET>
 __device__ __forceinline__ void channel_sums(const char* row, GET&& get, float* acc) {
     static_assert(BASIS > 1, "SH / SG / ASG sizes only");
     {
@@ -498,10 +503,10 @@ __device__ __forceinline__ void channel_sums(const char* row, GET&& get, float* 
         acc[1] = coef_mul<1 * BASIS>(b0, w1);
         acc[2] = coef_mul<2 * BASIS>(b0, w2);
     }
-    if constexpr (BASIS == 25) add_group<FMA, BASIS, 16, 24>(row, get, acc);
-    if constexpr (BASIS >= 16) add_group<FMA, BASIS, 9, 15>(row, get, acc);
-    if constexpr (BASIS >= 9) add_group<FMA, BASIS, 4, 8>(row, get, acc);
-    if constexpr (BASIS >= 4) add_group<FMA, BASIS, 1, 3>(row, get, acc);
+    if constexpr (BASIS == 25) add_group<FMA, BASIS, 16, 24, FENCE>(row, get, acc);
+    if constexpr (BASIS >= 16) add_group<FMA, BASIS, 9, 15, FENCE>(row, get, acc);
+    if constexpr (BASIS >= 9) add_group<FMA, BASIS, 4, 8, FENCE>(row, get, acc);
+    if constexpr (BASIS >= 4) add_group<FMA, BASIS, 1, 3, FENCE>(row, get, acc);
 }
 
 __device__ __forceinline__ uint32_t quant8(float v) {
@@ -512,6 +517,10 @@ __device__ __forceinline__ uint32_t quant8(float v) {
     if (s >= 2147483648.f || s < -2147483648.f) return 0u;
     return (uint32_t)(int32_t)s & 0xFFu;
 }
+
+typedef __attribute__((address_space(1))) uint32_t vr_gword_t;   // a dword of a frame buffer
+typedef float vr_f4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) vr_f4_t vr_gfloat4_t;
 
 __device__ __forceinline__ bool wave_any(bool v) { return __builtin_amdgcn_ballot_w64(v) != 0ull; }
 
@@ -765,9 +774,12 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
         float* accum = p.frames[frame].accum;
         if (accum) {
             const int64_t pix = (int64_t)(xy >> 16) * p.width + (int64_t)(xy & 0xFFFFu);
-            reinterpret_cast<float4*>(accum)[pix] = make_float4(out[0], out[1], out[2], out[3]);
+            // (frame buffers are global memory: say so, a pointer read from a table is "flat" to the
+            // compiler and would be accessed with flat_ instructions)
+            ((vr_gfloat4_t*)accum)[pix] = (vr_f4_t){out[0], out[1], out[2], out[3]};
         }
     }
+    vr_gword_t* const gpx = (vr_gword_t*)px;
     // composite, volrend.cu:152-172
     const float nalpha = 1.f - out[3];
     if (p.offscreen) {
@@ -775,13 +787,12 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
         out[1] = P::madd(p.background_brightness, nalpha, out[1]);
         out[2] = P::madd(p.background_brightness, nalpha, out[2]);
     } else {
-        const uint32_t init = *reinterpret_cast<const uint32_t*>(px);
+        const uint32_t init = *gpx;
         out[0] = P::madd((float)(init & 0xFFu) / 255.f, nalpha, out[0]);
         out[1] = P::madd((float)((init >> 8) & 0xFFu) / 255.f, nalpha, out[1]);
         out[2] = P::madd((float)((init >> 16) & 0xFFu) / 255.f, nalpha, out[2]);
     }
-    *reinterpret_cast<uint32_t*>(px) =
-        quant8(out[0]) | (quant8(out[1]) << 8) | (quant8(out[2]) << 16) | 0xFF000000u;
+    *gpx = quant8(out[0]) | (quant8(out[1]) << 8) | (quant8(out[2]) << 16) | 0xFF000000u;
 }
 
 // ---------------------------------------------------------------------------
@@ -848,7 +859,7 @@ constexpr int kOwnerQ = 4;
 // The record requests of one pass of a shade round (see Stage): lane l fetches 16-byte chunk
 // l % V of record l / V of its instruction, straight into the stage rows.  NT = the non-temporal
 // cache policy (an immediate of the instruction, hence a template parameter).
-template <int BASIS, bool NT>
+template <int BASIS, bool NT, int RING = kRing>
 __device__ __forceinline__ void issue_records(const KParams& p, char* stage, const uint32_t* it_leaf,
                                               uint32_t ring_head, int lane, int n, int pass) {
     using ST = Stage<BASIS>;
@@ -858,16 +869,19 @@ __device__ __forceinline__ void issue_records(const KParams& p, char* stage, con
         const int item = pass * ST::kPass + rin;
         if (lane < ST::kPerInstr * ST::kVec && rin < ST::kPass && item < n) {
 #if VR_ABLATE == 5   // timing experiment only: every record comes from a 128 KB window
-            const uint32_t leaf = it_leaf[(ring_head + (uint32_t)item) & (kRing - 1)] & 0x3FFu;
+            const uint32_t leaf = it_leaf[(ring_head + (uint32_t)item) & (RING - 1)] & 0x3FFu;
 #else
-            const uint32_t leaf = it_leaf[(ring_head + (uint32_t)item) & (kRing - 1)];
+            const uint32_t leaf = it_leaf[(ring_head + (uint32_t)item) & (RING - 1)];
 #endif
             const char* src = reinterpret_cast<const char*>(p.leaves) +
                               (uint64_t)leaf * (uint32_t)(p.leaf_stride_h * 2) + (lane % ST::kVec) * 16;
 #if VR_ABLATE != 4   // 4 = timing experiment only: no record fetch at all
-            __builtin_amdgcn_global_load_lds((vr_gptr_t)src,
-                                             (vr_lptr_t)(stage + k * ST::kPerInstr * ST::kRow), 16, 0,
-                                             NT ? 2 /* nt */ : 0);
+            // (the LDS address is formed in address space 3: a generic-pointer detour between two
+            // casts does not fold when `stage` is not the first LDS object of the kernel)
+            __builtin_amdgcn_global_load_lds(
+                (vr_gptr_t)src,
+                (vr_lptr_t)((__attribute__((address_space(3))) char*)stage + k * ST::kPerInstr * ST::kRow),
+                16, 0, NT ? 2 /* nt */ : 0);
 #endif
         }
     }
@@ -942,6 +956,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
              st_fin_r = 0, st_fin_l = 0, st_iter = 0;
 
 #if VR_TIMELINE
+    // (TL_MARK / TL_ADD: defined once below, they use the enclosing function's tl_mark)
     unsigned long long tl_refill = 0, tl_march = 0, tl_shade_load = 0, tl_shade_math = 0,
                        tl_shade_acc = 0, tl_total0 = __builtin_readcyclecounter(), tl_mark = 0,
                        tl_drained = 0;  // when this wave found the ray queue empty
@@ -1340,6 +1355,569 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// render_ms_kernel: the FAST flavours with the march and the shade phase on SEPARATE waves.
+//
+// render_kernel above alternates the two phases inside one wave, so the wave's march loads
+// are not in flight while it shades (march = 62 % of a C1 wave's life) and its register
+// allocation is the union of both phases' state (SH16: 96 VGPRs = 5 waves per SIMD).  Here a
+// workgroup is a PAIR of waves that talk through LDS only:
+//   wave 0 "march" : owns 64 rays (rt_core.cuh:108-188 without the colour arithmetic): position,
+//       lookup, attenuation, light, stop test.  A hit sample becomes an item (leaf, weight,
+//       owner lane, per-lane sequence number) in an LDS ring.  A finished ray is retired AT ONCE
+//       (no wait for its colour) through an event: (light, stopped, id of the lane's next ray).
+//       No basis, no colour state, no shade temporaries: ~45 VGPRs.
+//   wave 1 "shade" : lane j keeps the colour state of march lane j's ray (out[3], basis_fn, the
+//       pixel address).  It consumes the ring in order, 64 items at a time -- record DMA, SH
+//       arithmetic, sigmoid exactly as shade_chunk above -- adds each lane's contributions in
+//       sequence order (= sample order, rt_core.cuh:161), and on an event composites /
+//       quantises / stores the finished pixel and loads the next ray's basis.
+// The march wave never waits for colour work unless the ring is full or one ray has
+// kMsOutstanding items in flight; the shade wave has slack (its phases were 35 % of the fused
+// wave's time).  Per-ray arithmetic and its order are unchanged, so the results are the same bits.
+//
+// LDS protocol (single producer, single consumer; every word has exactly one writer):
+//   it_leaf / it_w / it_own[kMsRing]  ring entries, written by march before `tail` moves past them
+//   tail   (march -> shade)  entries [head, tail) are valid
+//   head   (shade -> march)  entries below head are free
+//   cons[64] (shade -> march) items of lane j consumed so far (mod 256): lane j may push while
+//            pushed - cons < kMsOutstanding, which bounds the per-owner table below
+//   ev_*   (march -> shade)  payload of ONE event batch; its ring entry is a marker
+//            (leaf = kMsMarker).  march posts the next batch only after ev_done caught up.
+//   flags  (march -> shade)  bit0: march is waiting for the shade wave (shade a partial chunk
+//            instead of waiting for 64 items), bit1: march has finished.
+// Both waves only ever spin on the OTHER wave of their own workgroup (co-resident by
+// construction); march-side waits are bounded and trip the status word instead of hanging.
+// ---------------------------------------------------------------------------
+#ifndef VR_MS_RING
+#define VR_MS_RING 256
+#endif
+#ifndef VR_MS_MIN_CHUNK
+#define VR_MS_MIN_CHUNK 64  // items the shade wave waits for while the march wave is producing
+#endif
+constexpr int kMsRing = VR_MS_RING;   // ring entries (positions are compared mod 2^32)
+constexpr int kMsOutstanding = 8;     // items one lane may have in the ring
+constexpr uint32_t kMsMarker = 0xFFFFFFFFu;
+constexpr uint32_t kMsNoRay = 0x7FFFFFFFu;
+constexpr uint32_t kMsSpinCap = 1u << 22;  // polls before a march-side wait gives up (~0.1 s)
+
+__device__ __forceinline__ void lds_fence() {  // LDS accesses of this wave issued so far are done
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void mem_fence() {  // ... and its global loads / LDS-DMAs have landed
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+// the protocol words are read / written as plain volatile LDS dwords (address space 3: no generic
+// pointer, no address-space test in the generated code)
+typedef __attribute__((address_space(3))) volatile uint32_t vr_lds_word_t;
+#define lds_peek(var) (*(const vr_lds_word_t*)&(var))
+#define lds_post(var, v) (*(vr_lds_word_t*)&(var) = (v))
+
+// Register budget per flavour (waves per SIMD; a pair needs two).
+template <int BASIS>
+constexpr int ms_min_waves() {
+    return BASIS == BASIS_25 ? 4 : BASIS == BASIS_16 ? VR_MS_SH16_WAVES : BASIS == BASIS_9 ? VR_MS_SH9_WAVES : 8;
+}
+template <int BASIS>
+constexpr int ms_lds_bytes() {
+    return kMsRing * 10 + Stage<BASIS>::kBytes + kWave * (1 + kMsOutstanding + 8) + 64;
+}
+template <int BASIS>
+constexpr int ms_pairs_per_cu() {
+    const int lds = ((ms_lds_bytes<BASIS>() + 511) / 512) * 512;
+    const int by_lds = 163840 / lds, by_reg = 2 * ms_min_waves<BASIS>();
+    return by_lds < by_reg ? by_lds : by_reg;
+}
+
+template <int FMA, int BASIS>
+__global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_kernel(
+    const KParams p) {
+    using P = Policy<FMA>;
+    constexpr int NB = BASIS > 1 ? BASIS : 1;
+    constexpr bool HAS_BASIS = BASIS != BASIS_RGBA;
+    constexpr uint32_t RM = kMsRing - 1;
+    using ST = Stage<BASIS>;
+    __shared__ uint32_t it_leaf[kMsRing];
+    __shared__ float it_w[kMsRing];
+    __shared__ uint16_t it_own[kMsRing];  // owner lane | (sequence number & 7) << 8
+    __shared__ uint32_t c_tail, c_head, c_flags, c_ev_done;
+    __shared__ uint32_t ev_mask[2];
+    __shared__ float ev_light[kWave];
+    __shared__ uint32_t ev_word[kWave];   // id of the lane's next ray (kMsNoRay: none) | stopped << 31
+    __shared__ uint8_t cons[kWave];
+    __shared__ __attribute__((aligned(8))) uint8_t table[kWave][kMsOutstanding];
+    __shared__ __attribute__((aligned(16))) char stage[ST::kBytes];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    if (threadIdx.x == 0) {
+        c_tail = 0u;
+        c_head = 0u;
+        c_flags = 0u;
+        c_ev_done = 0u;
+    }
+    if (threadIdx.x < kWave) {
+        cons[lane] = 0;
+        *reinterpret_cast<unsigned long long*>(table[lane]) = ~0ull;
+    }
+    __syncthreads();  // the only barrier: from here on the two waves run asynchronously
+    const int wpr = kRayWords + p.basis_words;
+
+    if (threadIdx.x < kWave) {
+        // =========================== march wave ===========================
+        float cen[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 0.f}, invdir[3] = {1.f, 1.f, 1.f};
+        float t = 0.f, tmax = -1.f, delta_scale = 1.f, light = 1.f;
+        bool active = false, alive = false, stopped = false;
+        Cursor cur;
+        uint32_t pushed = 0;  // items this LANE has pushed so far (all its rays; compared mod 256)
+        uint32_t tail = 0, ev_posted = 0;
+        uint32_t rounds = 0, progress_round = 0;
+        bool exhausted = false, aborted = false;
+        uint32_t chunk_next = 0, chunk_end = 0;
+        const uint32_t total = *p.ray_count;
+        uint32_t flags_now = 0;
+#if VR_TIMELINE
+        unsigned long long tl_mark = __builtin_readcyclecounter(), tl_m_refill = 0, tl_m_march = 0,
+                           tl_m_stall = 0;
+#endif
+        auto give_up = [&]() {  // a wait on the shade wave ran into its cap: report, stop
+            if (p.status) atomicOr(p.status, 2u);
+            aborted = true;
+        };
+
+        while (!aborted) {
+            TL_ADD(tl_m_march);
+            // ---- retire finished rays, hand their lanes new ones ----
+            const bool done = active && !alive;
+            const unsigned long long m_done = __builtin_amdgcn_ballot_w64(done);
+            const unsigned long long m_free = __builtin_amdgcn_ballot_w64(!active);
+            const unsigned long long m_live = __builtin_amdgcn_ballot_w64(active && alive);
+            const int n_avail = __builtin_popcountll(m_done | m_free);
+            if (n_avail > 0 && (m_live == 0ull || (!exhausted && n_avail >= p.refill_min))) {
+                progress_round = rounds;
+                if (!exhausted && chunk_next >= chunk_end) {  // (same queue protocol as render_kernel)
+                    uint32_t lo = 0, hi = 0;
+                    if (lane == 0) {
+                        const uint32_t nq = (uint32_t)p.n_queues;
+                        const uint32_t mine = blockIdx.x % nq;
+                        const uint32_t waves_per_q = (gridDim.x + nq - 1) / nq;
+                        for (uint32_t a = 0; a < nq; ++a) {
+                            const uint32_t x = (mine + a) % nq;
+                            const uint32_t qlo = (uint32_t)((uint64_t)total * x / nq);
+                            const uint32_t qhi = (uint32_t)((uint64_t)total * (x + 1) / nq);
+                            const uint32_t len = qhi - qlo;
+                            uint32_t* head = p.queue_head + x * kQueueStride;
+                            const uint32_t seen =
+                                __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (seen >= len) continue;
+                            uint32_t size = (len - seen) / (2u * waves_per_q);
+                            size = size < 64u ? 64u
+                                              : (size > (uint32_t)p.chunk_max ? (uint32_t)p.chunk_max : size);
+                            size &= ~63u;
+                            const uint32_t base = atomicAdd(head, size);
+                            if (base < len) {
+                                lo = qlo + base;
+                                hi = base + size < len ? qlo + base + size : qhi;
+                                break;
+                            }
+                        }
+                    }
+                    lo = __builtin_amdgcn_readfirstlane(lo);
+                    hi = __builtin_amdgcn_readfirstlane(hi);
+                    if (hi == lo) {
+                        exhausted = true;
+                    } else {
+                        chunk_next = lo;
+                        chunk_end = hi;
+                    }
+                }
+                const bool vacant = done || !active;
+                bool take = false;
+                uint32_t r = 0;
+                if (!exhausted) {
+                    const unsigned long long idle = m_done | m_free;
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
+                        (uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    r = chunk_next + rank;
+                    const uint32_t left = chunk_end - chunk_next;
+                    take = vacant && r < chunk_end;
+                    chunk_next += (uint32_t)n_avail < left ? (uint32_t)n_avail : left;
+                }
+                // the new rays are requested first, the event is posted while they travel
+                if (take) {
+                    const uint32_t* rs = ray_slot(p.ray_buf, wpr, r);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        cen[i] = u2f(ray_word(rs, 0 + i));
+                        dir[i] = u2f(ray_word(rs, 3 + i));
+                        invdir[i] = u2f(ray_word(rs, 6 + i));
+                    }
+                    t = u2f(ray_word(rs, 9));
+                    tmax = u2f(ray_word(rs, 10));
+                    delta_scale = u2f(ray_word(rs, 11));
+                }
+                const bool ev = done || take;
+                const unsigned long long m_ev = __builtin_amdgcn_ballot_w64(ev);
+                if (m_ev != 0ull) {
+                    // one event batch at a time: the shade wave must have taken the previous one,
+                    // and the ring needs a free entry for the marker
+                    uint32_t spins = 0;
+                    while (lds_peek(c_ev_done) != ev_posted ||
+                           tail - lds_peek(c_head) >= (uint32_t)kMsRing) {
+                        if (!(flags_now & 1u)) {
+                            flags_now |= 1u;
+                            if (lane == 0) lds_post(c_flags, flags_now);
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > kMsSpinCap) {
+                            give_up();
+                            break;
+                        }
+                    }
+                    if (aborted) break;
+                    if (ev) {
+                        ev_light[lane] = light;
+                        ev_word[lane] = (take ? r : kMsNoRay) | ((done && stopped) ? 0x80000000u : 0u);
+                    }
+                    if (lane == 0) {
+                        ev_mask[0] = (uint32_t)m_ev;
+                        ev_mask[1] = (uint32_t)(m_ev >> 32);
+                        it_leaf[tail & RM] = kMsMarker;
+                    }
+                    lds_fence();
+                    tail += 1u;
+                    ev_posted += 1u;
+                    if (lane == 0) lds_post(c_tail, tail);
+                }
+                if (vacant) {
+                    active = alive = take;
+                    light = 1.f;
+                    stopped = false;
+                    cur = Cursor();
+                }
+            }
+            if (!wave_any(active)) {
+                if (exhausted) break;
+                continue;
+            }
+
+            // ---- march ----
+            TL_ADD(tl_m_refill);
+            uint32_t spins = 0;
+            for (int m = 0; m < p.march_max;) {
+                const bool want = active && alive;
+                if (!wave_any(want)) break;
+                const uint32_t c = *(const __attribute__((address_space(3))) volatile uint8_t*)&cons[lane];
+                const uint32_t head = lds_peek(c_head);
+                const bool go = want && ((pushed - c) & 0xFFu) < (uint32_t)kMsOutstanding;
+                if (!wave_any(go) || tail - head > (uint32_t)(kMsRing - kWave)) {
+                    // every marching ray has kMsOutstanding items in flight, or the ring is full:
+                    // tell the shade wave not to wait for a full chunk, and poll
+                    if (!(flags_now & 1u)) {
+                        flags_now |= 1u;
+                        if (lane == 0) lds_post(c_flags, flags_now);
+                    }
+                    TL_ADD(tl_m_march);
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kMsSpinCap) {
+                        give_up();
+                        break;
+                    }
+                    TL_ADD(tl_m_stall);
+                    continue;
+                }
+                spins = 0;
+                if (flags_now & 1u) {
+                    flags_now &= ~1u;
+                    if (lane == 0) lds_post(c_flags, flags_now);
+                }
+                ++m;
+                // guard against rays that never end, as in render_kernel
+                if (((++rounds) & 1023u) == 0u && rounds - progress_round >= (uint32_t)kMaxIter) {
+                    asm volatile("" ::: "memory");
+                    if (active && alive) {
+                        alive = false;
+                        if (p.status) atomicOr(p.status, 1u);
+                    }
+                    progress_round = rounds;
+                }
+                bool push = false;
+                uint32_t leaf = 0;
+                float weight = 0.f;
+                if (go) {
+                    float pos[3];
+                    pos[0] = P::madd(t, dir[0], cen[0]);
+                    pos[1] = P::madd(t, dir[1], cen[1]);
+                    pos[2] = P::madd(t, dir[2], cen[2]);
+                    int levels;
+                    uint32_t word;
+                    leaf = query_n2<false>(p, pos, &levels, &word, cur);
+                    const float dda = dda_unit<FMA>(pos, invdir);
+                    const float t_subcube = __builtin_amdgcn_ldexpf(dda, -levels);
+                    const float delta_t = t_subcube + p.step_size;
+                    const float sigma = h2f((uint16_t)(word & 0xFFFFu));
+                    bool stop = false;
+                    if (sigma > p.sigma_thresh) {  // rt_core.cuh:118-121,174
+                        const float att = vr_expf(-delta_t * delta_scale * sigma);
+                        weight = light * (1.f - att);
+                        push = true;
+                        light *= att;
+                        stop = light < p.stop_thresh;
+                    }
+                    if (stop) {
+                        stopped = true;
+                        alive = false;
+                    } else {
+                        t += delta_t;
+                        alive = t < tmax;
+                    }
+                }
+                const unsigned long long m_push = __builtin_amdgcn_ballot_w64(push);
+                if (m_push != 0ull) {
+                    if (push) {
+                        const uint32_t seq =
+                            tail + __builtin_amdgcn_mbcnt_hi(
+                                       (uint32_t)(m_push >> 32),
+                                       __builtin_amdgcn_mbcnt_lo((uint32_t)m_push, 0u));
+                        const uint32_t j = seq & RM;
+                        it_leaf[j] = leaf;
+                        it_w[j] = weight;
+                        it_own[j] = (uint16_t)((uint32_t)lane | ((pushed & 7u) << 8));
+                        pushed += 1u;
+                    }
+                    tail += (uint32_t)__builtin_popcountll(m_push);
+                    lds_fence();  // the entries are written before the tail moves past them
+                    if (lane == 0) lds_post(c_tail, tail);
+                }
+            }
+        }
+#if VR_TIMELINE
+        if (p.sched_stats && lane == 0) {
+            atomicAdd(&p.sched_stats[0], tl_m_refill);
+            atomicAdd(&p.sched_stats[1], tl_m_march);
+            atomicAdd(&p.sched_stats[2], tl_m_stall);
+            atomicAdd(&p.sched_stats[7], 1ull);
+        }
+#endif
+        lds_fence();
+        if (lane == 0) lds_post(c_flags, 2u);  // finished: everything this wave will ever post is visible
+    } else {
+        // =========================== shade wave ===========================
+        float* const res = reinterpret_cast<float*>(stage);  // 3 x 64 floats over the consumed rows
+        float mybasis[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) mybasis[i] = 0.f;
+        float out[3] = {0.f, 0.f, 0.f};
+        uint32_t my_ray = 0;  // id of the ray whose colour this lane keeps
+        bool s_active = false;
+        uint32_t nseq = 0;  // items of this lane consumed so far
+        uint32_t head = 0, ev_done = 0;
+#if VR_TIMELINE
+        unsigned long long tl_mark = __builtin_readcyclecounter(), tl_s_idle = 0, tl_s_event = 0,
+                           tl_s_dma = 0, tl_s_math = 0;
+#endif
+
+        for (;;) {
+            const uint32_t flags = lds_peek(c_flags);
+            lds_fence();  // (flags is read before tail: "finished" implies the final tail)
+            const uint32_t tail = lds_peek(c_tail);
+            asm volatile("" ::: "memory");  // ring entries are read after the tail that covers them
+            const uint32_t avail = tail - head;
+            // (one structured if / else chain and a single back edge: with `continue`s the
+            // compiler keeps two copies of the lane state and shuffles them at every loop end)
+            if (avail == 0u && (flags & 2u)) break;
+            int n = avail < (uint32_t)ST::kShade ? (int)avail : ST::kShade;
+            const uint32_t jmine = (head + (uint32_t)lane) & RM;
+            const uint32_t myleaf = lane < n ? it_leaf[jmine] : 0u;
+            const unsigned long long m_marker =
+                __builtin_amdgcn_ballot_w64(lane < n && myleaf == kMsMarker);
+            if (m_marker != 0ull && !(m_marker & 1ull)) n = __builtin_ctzll(m_marker);  // items in front of a marker
+            if (avail == 0u || (m_marker == 0ull && n < (VR_MS_MIN_CHUNK < ST::kShade ? VR_MS_MIN_CHUNK : ST::kShade) && !(flags & 3u))) {
+                // nothing to do yet / the march wave is busy producing: wait for a full chunk
+                __builtin_amdgcn_s_sleep(1);
+                TL_ADD(tl_s_idle);
+            } else if (m_marker & 1ull) {
+                // ---- event batch: finish pixels, take over the lanes' next rays ----
+                asm volatile("" ::: "memory");
+                const unsigned long long mask =
+                    (unsigned long long)ev_mask[0] | ((unsigned long long)ev_mask[1] << 32);
+                if ((mask >> lane) & 1ull) {
+                    const uint32_t w = ev_word[lane];
+                    const uint32_t r = w & 0x7FFFFFFFu;
+                    // one memory round trip for the whole batch: the finished ray's pixel address
+                    // (its words of the ray buffer; only the ray id is kept while it marches) and
+                    // the next ray's basis are requested together
+                    uint32_t px_lo = 0, px_hi = 0, fin_xy = 0, fin_frame = 0;
+                    if (s_active) {
+                        const uint32_t* rs = ray_slot(p.ray_buf, wpr, my_ray);
+                        px_lo = ray_word(rs, 13);
+                        px_hi = ray_word(rs, 14);
+                        if (p.any_accum) {
+                            fin_xy = ray_word(rs, 12);
+                            fin_frame = ray_word(rs, 15);
+                        }
+                    }
+                    // (the old ray's basis is dead: the new one loads straight into its registers)
+                    if (HAS_BASIS && r != kMsNoRay) {
+                        const uint32_t* rs = ray_slot(p.ray_buf, wpr, r);
+#pragma unroll
+                        for (int i = 0; i < NB; ++i) mybasis[i] = u2f(ray_word(rs, kRayWords + i));
+                    }
+                    if (s_active) {
+                        Ray ray;
+                        ray.out[0] = out[0];
+                        ray.out[1] = out[1];
+                        ray.out[2] = out[2];
+                        ray.out[3] = 0.f;
+                        ray.light = ev_light[lane];
+                        ray.stopped = (w >> 31) != 0u;
+                        ray.entered = true;
+                        RayCounters z;
+                        finish_ray<FMA, false>(
+                            p, ray, z,
+                            reinterpret_cast<uint8_t*>(((uint64_t)px_hi << 32) | (uint64_t)px_lo),
+                            fin_xy, (int)fin_frame);
+                    }
+                    s_active = r != kMsNoRay;
+                    my_ray = r;
+                    out[0] = out[1] = out[2] = 0.f;
+                }
+                head += 1u;
+                ev_done += 1u;
+                lds_fence();  // the payload has been read before the march wave may overwrite it
+                if (lane == 0) {
+                    lds_post(c_head, head);
+                    lds_post(c_ev_done, ev_done);
+                }
+                TL_ADD(tl_s_event);
+            } else {
+            // ---- colour of n items, one per lane (shade_chunk of render_kernel) ----
+            // (the per-lane address terms below are loop invariants the compiler would rather keep
+            // in -- and then spill from -- registers than recompute: hide the lane id from it)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const bool have = lane < n;
+            const float weight = have ? it_w[jmine] : 0.f;
+            const uint32_t ownw = have ? (uint32_t)it_own[jmine] : (uint32_t)lane;
+            const int own4 = (int)(ownw & 63u) << 2;
+            auto basis_of = [&](int i) -> float {
+                return u2f((uint32_t)__builtin_amdgcn_ds_bpermute(own4, (int)f2u(mybasis[i])));
+            };
+            float bfull[ST::kPasses > 1 ? NB : 1];
+            if constexpr (ST::kPasses > 1) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) bfull[i] = basis_of(i);
+            }
+            auto basis_get = [&](int i) -> float {
+                if constexpr (ST::kPasses > 1) return bfull[i];
+                else return basis_of(i);
+            };
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#if VR_ABLATE == 7   // timing experiment only: the shade wave consumes items without colour work
+            r0 = r1 = r2 = weight;
+            if constexpr (false) {
+#else
+            if constexpr (ST::kEnabled) {
+#endif
+#pragma unroll
+                for (int pass = 0; pass < ST::kPasses; ++pass) {
+                    if (pass * ST::kPass < n) {
+                        if (p.records_nt)
+                            issue_records<BASIS, true, kMsRing>(p, stage, it_leaf, head, ln, n, pass);
+                        else
+                            issue_records<BASIS, false, kMsRing>(p, stage, it_leaf, head, ln, n, pass);
+                        TL_ADD(tl_s_math);
+                        mem_fence();  // the DMAs have landed
+                        TL_ADD(tl_s_dma);
+                        if (ST::kPasses == 1 || ln / ST::kPass == pass) {
+                            const char* row = stage + (ln % ST::kPass) * ST::kRow;
+                            float acc[3];
+                            channel_sums<FMA, BASIS, (BASIS >= 16)>(row, basis_get, acc);
+                            if constexpr (VR_PACKED_EXP) {
+                                const float2v e01 = vr_expf2((float2v){-acc[0], -acc[1]}) + splat2(1.f);
+                                r0 = weight / e01.x;
+                                r1 = weight / e01.y;
+                            } else {
+                                r0 = weight / (1.f + vr_expf(-acc[0]));
+                                r1 = weight / (1.f + vr_expf(-acc[1]));
+                            }
+                            r2 = weight / (1.f + vr_expf(-acc[2]));
+                        }
+                        if (ST::kPasses > 1) lds_fence();  // rows are free for the next pass
+                    }
+                }
+            } else {
+                const float b0 = HAS_BASIS ? basis_of(0) : 0.f;
+                if (have) {
+                    Record<BASIS> rec;
+                    load_record<BASIS>(p, myleaf, rec);
+                    if (HAS_BASIS) {
+                        r0 = weight / (1.f + vr_expf(-(b0 * rec.at(0))));
+                        r1 = weight / (1.f + vr_expf(-(b0 * rec.at(1))));
+                        r2 = weight / (1.f + vr_expf(-(b0 * rec.at(2))));
+                    } else {
+                        r0 = rec.at(0);
+                        r1 = rec.at(1);
+                        r2 = rec.at(2);
+                    }
+                }
+            }
+            lds_fence();  // every row has been read: `res` may overwrite them
+            if (have) {
+                res[0 * kWave + lane] = r0;
+                res[1 * kWave + lane] = r1;
+                res[2 * kWave + lane] = r2;
+                table[ownw & 63u][(ownw >> 8) & 7u] = (uint8_t)lane;
+            }
+            lds_fence();
+            // each owner adds the contributions of its own items in sequence order: its items of
+            // this chunk carry the sequence numbers nseq, nseq + 1, ... (at most kMsOutstanding)
+            const unsigned long long row8 = *reinterpret_cast<const unsigned long long*>(table[ln]);
+            uint32_t taken = 0;
+#pragma unroll 1
+            for (int d = 0; d < kMsOutstanding; ++d) {
+                const uint32_t e = (uint32_t)(row8 >> (((nseq + (uint32_t)d) & 7u) * 8u)) & 0xFFu;
+                const bool mine = e != 0xFFu;
+                if (!wave_any(mine)) break;
+                if (mine) {
+                    if (HAS_BASIS) {
+                        out[0] += res[0 * kWave + e];
+                        out[1] += res[1 * kWave + e];
+                        out[2] += res[2 * kWave + e];
+                    } else {
+                        const float w = it_w[(head + e) & RM];
+                        out[0] = P::madd(res[0 * kWave + e], w, out[0]);
+                        out[1] = P::madd(res[1 * kWave + e], w, out[1]);
+                        out[2] = P::madd(res[2 * kWave + e], w, out[2]);
+                    }
+                    taken += 1u;
+                }
+            }
+            if (taken) {
+                uint32_t ones = 0xFFFFFFFFu;
+                asm volatile("" : "+v"(ones));  // (a constant pair would be hoisted and spilled)
+                reinterpret_cast<uint32_t*>(table[ln])[0] = ones;
+                reinterpret_cast<uint32_t*>(table[ln])[1] = ones;
+                nseq += taken;
+                cons[ln] = (uint8_t)nseq;
+            }
+            head += (uint32_t)n;
+            lds_fence();
+            if (lane == 0) lds_post(c_head, head);
+            TL_ADD(tl_s_math);
+            }
+        }
+#if VR_TIMELINE
+        if (p.sched_stats && lane == 0) {
+            atomicAdd(&p.sched_stats[3], tl_s_idle);
+            atomicAdd(&p.sched_stats[4], tl_s_event);
+            atomicAdd(&p.sched_stats[5], tl_s_dma);
+            atomicAdd(&p.sched_stats[6], tl_s_math);
+        }
+#endif
+    }
+}
+
 // ---------------------------------------------------------------------------
 // raygen_kernel: one lane per pixel of every frame of the launch, at full occupancy.
 // Ray generation, NDC warp, world->tree transform, view-direction rotation and the
@@ -1697,7 +2275,7 @@ __global__ void build_bricks_kernel(const uint32_t* nodes, const int32_t* brick_
 // grid = the persistent waves: as many as the chip holds of this flavour (or the tuning
 // override), but no more than about one wave per 128 rays of a small launch
 template <int FMA, int MODE>
-hipError_t launch_basis(const KParams& p, int64_t want, int n_cus, int waves_override,
+hipError_t launch_basis(const KParams& p, int64_t want, int n_cus, int waves_override, int split,
                         hipStream_t s) {
     const dim3 block(kWave);
     int b;
@@ -1712,12 +2290,21 @@ hipError_t launch_basis(const KParams& p, int64_t want, int n_cus, int waves_ove
             default: b = BASIS_1; break;
         }
     }
+    // split != 0 (FAST flavours only): march and shade on separate waves, render_ms_kernel;
+    // a workgroup is a pair of waves, the grid counts pairs
 #define VR_LAUNCH(B)                                                                         \
     do {                                                                                     \
-        const int64_t cap_ = (int64_t)n_cus * (waves_override > 0 ? waves_override           \
+        if (MODE == MODE_FAST && split) {                                                    \
+            const int64_t cap_ = (int64_t)n_cus * (waves_override > 0 ? (waves_override + 1) / 2 \
+                                                                      : ms_pairs_per_cu<B>()); \
+            const dim3 grid((unsigned)(want < cap_ ? want : cap_));                          \
+            hipLaunchKernelGGL((render_ms_kernel<FMA, B>), grid, dim3(2 * kWave), 0, s, p);  \
+        } else {                                                                             \
+            const int64_t cap_ = (int64_t)n_cus * (waves_override > 0 ? waves_override       \
                                                                   : waves_per_cu<B, MODE>()); \
-        const dim3 grid((unsigned)(want < cap_ ? want : cap_));                              \
-        hipLaunchKernelGGL((render_kernel<FMA, B, MODE>), grid, block, 0, s, p);             \
+            const dim3 grid((unsigned)(want < cap_ ? want : cap_));                          \
+            hipLaunchKernelGGL((render_kernel<FMA, B, MODE>), grid, block, 0, s, p);         \
+        }                                                                                    \
     } while (0)
     switch (b) {
         case BASIS_RGBA: VR_LAUNCH(BASIS_RGBA); break;
@@ -1732,13 +2319,14 @@ hipError_t launch_basis(const KParams& p, int64_t want, int n_cus, int waves_ove
 }
 
 template <int FMA>
-hipError_t launch_fp(const KParams& p, int64_t want, int n_cus, int waves_override, hipStream_t s) {
+hipError_t launch_fp(const KParams& p, int64_t want, int n_cus, int waves_override, int split,
+                     hipStream_t s) {
     const bool n2 = (p.N == 2) && p.top_levels > 0;  // built at upload when the tree qualifies
     const bool lobes = p.format == VR_FORMAT_SG || p.format == VR_FORMAT_ASG;
-    if (!n2) return launch_basis<FMA, MODE_GENERIC>(p, want, n_cus, waves_override, s);
+    if (!n2) return launch_basis<FMA, MODE_GENERIC>(p, want, n_cus, waves_override, 0, s);
     if (lobes || p.instrumented || p.render_depth)  // the depth visualisation lives outside FAST
-        return launch_basis<FMA, MODE_FULL>(p, want, n_cus, waves_override, s);
-    return launch_basis<FMA, MODE_FAST>(p, want, n_cus, waves_override, s);
+        return launch_basis<FMA, MODE_FULL>(p, want, n_cus, waves_override, 0, s);
+    return launch_basis<FMA, MODE_FAST>(p, want, n_cus, waves_override, split, s);
 }
 
 }  // namespace
@@ -1749,7 +2337,7 @@ hipError_t launch_prepare(const KParams& p, const FrameTable& tbl, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_override,
+hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_override, int split,
                          hipStream_t stream) {
     if (p.n_wave_blocks <= 0 || p.n_frames <= 0) return hipSuccess;
     const int64_t total_blocks = p.n_wave_blocks * p.n_frames;
@@ -1771,8 +2359,9 @@ hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_ove
     int64_t want = total_blocks / 2;  // about one wave per 64 rays that enter the volume
     if (want < 256) want = 256;
     if (want > total_blocks) want = total_blocks;
-    const hipError_t e = fp_mode == VR_FP_FMA ? launch_fp<1>(p, want, n_cus, waves_override, stream)
-                                              : launch_fp<0>(p, want, n_cus, waves_override, stream);
+    const hipError_t e = fp_mode == VR_FP_FMA
+                             ? launch_fp<1>(p, want, n_cus, waves_override, split, stream)
+                             : launch_fp<0>(p, want, n_cus, waves_override, split, stream);
     if (e != hipSuccess || !p.enable_probe || p.probe_disp_size <= 0) return e;
     const int side = p.probe_disp_size + 5;
     const dim3 pgrid((unsigned)((side * side + 255) / 256), (unsigned)p.n_frames);
