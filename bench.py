@@ -307,8 +307,8 @@ def main():
     opts = api.RenderOptions()
     fp_mode = _abi.FP_FMA if args.fp == "fma" else _abi.FP_STRICT
     stream = torch.cuda.current_stream()
-    if args.tune:
-        api.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
+    if args.tune:  # the scheduling knobs of THIS tree (results never depend on them)
+        tree.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
 
     # per-GPU work per launch shrinks with the tile shard: keep it up with more poses per launch
     B = max(1, min(args.batch * (1 if args.mode == "replicas" else world), _abi.MAX_BATCH))
@@ -520,8 +520,8 @@ def main():
 
     tune_kv = dict(kv.split("=") for kv in args.tune.split(",")) if args.tune else {}
     split = int(tune_kv["split"]) if "split" in tune_kv else int(os.environ.get("VR_SPLIT", "-1"))
-    if split < 0:  # the library's default (vr_api.cpp): SH25 keeps the fused kernel
-        split = int(cfg["basis_dim"] != 25)
+    if split < 0:  # the library's default (vr_api.cpp): split kernel for one-frame launches only
+        split = int(min(B, K) == 1 and cfg["basis_dim"] != 25)
     kernel_name = "render_ms_kernel" if split else "render_kernel"
     if rank == 0:
         # replicas: every rank rendered its own K frames; tile mode: the K frames were shared

@@ -67,7 +67,7 @@ class TileShardRenderer {
     uint8_t* gather_[2] = {nullptr, nullptr};   // root: [n_ranks][max_batch][compact_bytes]
     uint8_t* frames_[2] = {nullptr, nullptr};   // root: [max_batch][H][W][4]
     std::vector<void*> comm_;  // ncclComm_t per rank
-    std::string transport_;
+    std::string transport_, p2p_note_;
 };
 
 }  // namespace internal

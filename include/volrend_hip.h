@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define VR_ABI_VERSION 2
+#define VR_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------ */
 enum {
@@ -236,14 +236,25 @@ int vr_render_batch(vr_tree_t tree, int n_frames, const VrCamera* cams,
  * two alternating streams in two, so no later vr_render / vr_render_batch of that size (or
  * smaller, or tile-sharded) on them allocates or blocks.  Optional; synchronous. */
 int vr_reserve(vr_tree_t tree, int width, int height, int n_frames);
+/* The same for a tile-sharded render loop: the ray buffer of a launch holds its rank's tiles
+ * rounded up to WHOLE tiles (tile_w x tile_h as in VrFrame; 0, 0 = whole-frame tiles), which
+ * can exceed the frame-rounded size vr_reserve assumes when tile_h does not divide the height.
+ * n_slots launch slots are sized (1..8: one per stream that renders this tree concurrently). */
+int vr_reserve_tiles(vr_tree_t tree, int width, int height, int n_frames, int tile_w, int tile_h,
+                     int world, int n_slots);
 /* Sticky device status word of the tree's launches: bit 0 = some ray hit the 2^22-sample
  * guard (the reference would still be looping).  Synchronous; reset != 0 clears it.
  * vr_render* refuses step_size <= 0 / NaN (VR_ERR_INVALID_ARGUMENT), where the reference
  * hangs, so the bit only ever fires on pathological step_size / scene combinations. */
 int vr_tree_status(vr_tree_t tree, uint32_t* status, int reset);
-/* Scheduling knobs of the persistent kernel ("march_max", "refill_min",
- * "waves_per_cu"); results never depend on them. */
+/* Scheduling / layout knobs ("march_max", "refill_min", "waves_per_cu", "split", "records_nt",
+ * "top_levels", "brick_levels", ...); results never depend on them.  Every tree carries its own
+ * copy, taken at upload (or from the source of a clone) from the process defaults:
+ *   vr_set_tuning       changes the DEFAULTS of trees uploaded afterwards (serialised);
+ *   vr_tree_set_tuning  changes one tree (not the upload-time keys top_levels / brick_levels);
+ *                       takes effect with that tree's next launch, any thread. */
 int vr_set_tuning(const char* key, int value);
+int vr_tree_set_tuning(vr_tree_t tree, const char* key, int value);
 /* Scheduling tallies accumulated by instrumented launches (frames with counters):
  * [0] march rounds [1] lanes busy in them [2] shade rounds [3] lanes busy in them
  * [4] distinct leaves summed over shade rounds [5] retire rounds [6] rays retired in them [7] scheduler iterations.

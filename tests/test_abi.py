@@ -44,7 +44,7 @@ def test_every_header_symbol_is_exported(lib_path):
 def test_ctypes_prototypes_cover_the_header(lib_path):
     assert sorted(_abi.PROTOTYPES) == header_functions()
     L = _abi.lib()  # resolves every symbol; raises AttributeError otherwise
-    assert L.vr_abi_version() == _abi.ABI_VERSION == 2
+    assert L.vr_abi_version() == _abi.ABI_VERSION == 3
 
 
 def test_struct_layouts_match_the_c_compiler():
@@ -91,6 +91,9 @@ def test_host_only_entry_points(lib_path):
     assert b"multiples of 8" in L.vr_last_error()
     assert L.vr_set_tuning(b"no_such_knob", 1) != 0
     assert L.vr_set_tuning(b"march_max", 2) == 0
+    assert L.vr_set_tuning(b"march_max", 16) == 0   # (the default again: trees uploaded later copy it)
+    assert L.vr_tree_set_tuning(None, b"march_max", 2) != 0 and b"NULL" in L.vr_last_error()
+    assert L.vr_reserve_tiles(None, 800, 800, 1, 0, 0, 1, 2) != 0
     # argument validation happens before any device call
     assert L.vr_tree_upload(None, None) == 1
     d = _abi.VrTreeDesc()

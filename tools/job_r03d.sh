@@ -1,0 +1,11 @@
+set -u
+mkdir -p gpurun_out/r03d
+O=gpurun_out/r03d
+VR_TIMELINE=1 timeout 600 python tools/quick_ab.py --config C1 --variants roledbg0,tl --tunes "split=1" --frames 64 --reps 2 --out $O/dbg.jsonl > $O/dbg.log 2>&1
+timeout 900 python tools/quick_ab.py --config C1 --variants base,role0 --tunes "split=1;split=1,refill_min=8;split=1,refill_min=12;split=0,refill_min=24" --frames 64,20,1 --reps 3 --check --out $O/ab_c1.jsonl > $O/ab_c1.log 2>&1
+timeout 900 python tools/quick_ab.py --config C3 --variants base --tunes "split=1;split=1,refill_min=8;split=0,refill_min=24" --frames 16 --reps 3 --check --out $O/ab_c3.jsonl > $O/ab_c3.log 2>&1
+cat $O/*.jsonl | python -c '
+import json,sys
+for l in sys.stdin:
+    d=json.loads(l); print(d["config"], d["variant"], d["tune"], d["frames"], d["ms_per_frame_mean"], d["ms_per_frame_min"], d.get("same_as_first"), d.get("sched_stats"))'
+tail -3 $O/ab_c1.log

@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--fp", default="strict")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--rotate", action="store_true",
+                    help="every timed launch renders DIFFERENT poses (as the bench's timed region does); "
+                         "without it the same launch is repeated and finds its data warm in the caches")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
 
@@ -57,16 +60,19 @@ def main():
         tree = api.N3Tree.from_synth(stree)
         for tune in args.tunes.split(";"):
             if tune:
-                api.set_tuning(**{k: int(x) for k, x in (kv.split("=") for kv in tune.split(","))})
+                tree.set_tuning(**{k: int(x) for k, x in (kv.split("=") for kv in tune.split(","))})
             for nf in frames_list:
                 # poses offset like bench.py's timed region (warmup 64 / 5)
                 first = 64 if nf >= 64 else 5
-                pb = api.PreparedBatch(tree, cam, [transforms[(first + i) % 200] for i in range(nf)],
-                                       opts, [imgs[i] for i in range(nf)], True, fp_mode=fp_mode)
-                pb.launch(stream)
+                def batch(at):
+                    return api.PreparedBatch(tree, cam, [transforms[(at + i) % 200] for i in range(nf)],
+                                             opts, [imgs[i] for i in range(nf)], True, fp_mode=fp_mode)
+                pbs = [batch(first + (k * (nf + 7) if args.rotate else 0)) for k in range(args.reps + 1)]
+                pbs[-1].launch(stream)
                 torch.cuda.synchronize()
                 ms = []
-                for _ in range(args.reps):
+                for k in range(args.reps):
+                    pb = pbs[k]
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(stream)
                     pb.launch(stream)
@@ -75,6 +81,8 @@ def main():
                     ms.append(e0.elapsed_time(e1))
                 same = None
                 if args.check:
+                    pbs[0].launch(stream)
+                    torch.cuda.synchronize()
                     f0 = imgs[0].clone()
                     if ref_frame is None or nf not in ref_frame:
                         ref_frame = ref_frame or {}

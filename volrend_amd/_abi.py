@@ -63,7 +63,7 @@ class VrFrame(C.Structure):
                 ("counters", C.c_void_p)]
 
 
-ABI_VERSION = 2  # VR_ABI_VERSION of include/volrend_hip.h
+ABI_VERSION = 3  # VR_ABI_VERSION of include/volrend_hip.h
 MAX_BATCH = 512  # VR_MAX_BATCH
 
 COUNTER_FIELDS = ("rays", "rays_hit_box", "samples", "child_reads", "hit_samples", "alg_bytes",
@@ -93,8 +93,11 @@ PROTOTYPES = {
     "vr_render_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(VrCamera),
                                   C.POINTER(VrRenderOptions), C.POINTER(VrFrame), C.c_void_p]),
     "vr_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "vr_reserve_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int]),
     "vr_tree_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "vr_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "vr_tree_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "vr_sched_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 8), C.c_int]),
     "vr_touch_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "vr_touch_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 4), C.c_int]),

@@ -332,10 +332,22 @@ class N3Tree:
         _abi.check(_abi.lib().vr_touch_count(self.handle, C.byref(out), 1 if reset else 0))
         return dict(zip(("leaves", "nodes", "top", "bricks"), [int(v) for v in out]))
 
-    def reserve(self, width: int, height: int, n_frames: int) -> None:
-        """Pre-allocate the per-launch ray buffers (vr_reserve): no later launch of that
-        size blocks or allocates."""
-        _abi.check(_abi.lib().vr_reserve(self.handle, int(width), int(height), int(n_frames)))
+    def reserve(self, width: int, height: int, n_frames: int, shard: "TileShard | None" = None,
+                n_slots: int = 2) -> None:
+        """Pre-allocate the per-launch ray buffers (vr_reserve / vr_reserve_tiles): no later
+        launch of that size blocks or allocates."""
+        if shard is None and n_slots == 2:
+            _abi.check(_abi.lib().vr_reserve(self.handle, int(width), int(height), int(n_frames)))
+        else:
+            tw, th, world = (shard.tile_w, shard.tile_h, shard.world) if shard else (0, 0, 1)
+            _abi.check(_abi.lib().vr_reserve_tiles(self.handle, int(width), int(height),
+                                                   int(n_frames), tw, th, world, int(n_slots)))
+
+    def set_tuning(self, **kw) -> None:
+        """Scheduling knobs of THIS tree (vr_tree_set_tuning): march_max, refill_min,
+        waves_per_cu, split, records_nt, ...  Results never depend on them."""
+        for k, v in kw.items():
+            _abi.check(_abi.lib().vr_tree_set_tuning(self.handle, k.encode(), int(v)))
 
     def status(self, reset: bool = False) -> int:
         """Sticky device status word (vr_tree_status): bit 0 = a ray hit the sample guard."""
@@ -523,7 +535,8 @@ def launch_renderer_batch(tree: N3Tree, cam: Camera, transforms, options: Render
 
 
 def set_tuning(**kw) -> None:
-    """Scheduling knobs of the persistent kernel (march_max, refill_min, waves_per_cu)."""
+    """DEFAULT knobs of trees uploaded from now on (vr_set_tuning), incl. the upload-time
+    top_levels / brick_levels; an existing tree is changed with ``N3Tree.set_tuning``."""
     for k, v in kw.items():
         _abi.check(_abi.lib().vr_set_tuning(k.encode(), int(v)))
 

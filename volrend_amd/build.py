@@ -39,6 +39,10 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False, extra_flags=(), variant: str = "") -> str:
     """variant: experiment / profiling build next to the product library
     (libvolrend_hip_<variant>.so, selected at run time with VOLREND_HIP_LIB)."""
+    if not variant and any(f.startswith(("-DVR_ABLATE", "-DVR_TIMELINE", "-DVR_ROLE_DEBUG"))
+                           for f in extra_flags):
+        raise ValueError("experiment hooks (VR_ABLATE / VR_TIMELINE) never go into the product library: "
+                         "build them with --variant NAME")
     out = LIB if not variant else os.path.join(HERE, f"libvolrend_hip_{variant}.so")
     if not variant and not force and not needs_build():
         return LIB

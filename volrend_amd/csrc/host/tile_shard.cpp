@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <stdexcept>
 
 namespace volrend {
@@ -57,6 +58,29 @@ void TileShardRenderer::init(const N3Tree& tree, const TileShardConfig& cfg) {
     compact_bytes_ = vr_compact_bytes(width_, height_, tile_w_, tile_h_, n_);
     if (compact_bytes_ <= 0) throw std::runtime_error("TileShardRenderer: bad tile geometry");
 
+    // The gather sends every peer's tiles straight to the root GPU: that needs peer access
+    // (xGMI inside a node) between the root and each peer.  Without it RCCL falls back to
+    // staging through host memory -- correct but no longer the path this class exists for --
+    // so say so loudly instead of silently running 10x slower.  VOLREND_ALLOW_NO_P2P=1 proceeds.
+    if (!share_) {
+        std::string no_p2p;
+        for (int r = 1; r < n_; ++r) {
+            int to_root = 0, from_root = 0;
+            hip_ok(hipDeviceCanAccessPeer(&to_root, device_[r], device_[0]), "hipDeviceCanAccessPeer");
+            hip_ok(hipDeviceCanAccessPeer(&from_root, device_[0], device_[r]), "hipDeviceCanAccessPeer");
+            if (!to_root || !from_root) no_p2p += " " + std::to_string(device_[r]);
+        }
+        const char* allow = getenv("VOLREND_ALLOW_NO_P2P");
+        if (!no_p2p.empty() && !(allow && allow[0] == '1'))
+            throw std::runtime_error(
+                "TileShardRenderer: no peer access between the root GPU " + std::to_string(device_[0]) +
+                " and GPU(s)" + no_p2p + " (hipDeviceCanAccessPeer = 0): the RGBA8 gather and the "
+                "tree replicas would be staged through host memory.  Check `rocm-smi --showtopo`, "
+                "IOMMU / ACS settings and HSA_ENABLE_IPC_MODE_LEGACY=0; set VOLREND_ALLOW_NO_P2P=1 to "
+                "run anyway, or --share_gpu to rehearse on one device");
+        p2p_note_ = no_p2p.empty() ? "peer access to the root: yes"
+                                   : "NO peer access for GPU(s)" + no_p2p + " (host-staged)";
+    }
     int prev = 0;
     hip_ok(hipGetDevice(&prev), "hipGetDevice");
     VrTreeInfo info;
@@ -80,7 +104,9 @@ void TileShardRenderer::init(const N3Tree& tree, const TileShardConfig& cfg) {
             vr_ok(vr_tree_clone(tree.device, device_[r], &tree_[r]), "vr_tree_clone");
             owns_tree_[r] = true;
         }
-        vr_ok(vr_reserve(tree_[r], width_, height_, max_batch_), "vr_reserve");
+        // the rank's tiles, rounded up to whole tiles, one slot (one render stream per rank)
+        vr_ok(vr_reserve_tiles(tree_[r], width_, height_, max_batch_, tile_w_, tile_h_, n_, 1),
+              "vr_reserve_tiles");
         hipStream_t st;
         hip_ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
         render_stream_[r] = st;
@@ -110,7 +136,8 @@ void TileShardRenderer::init(const N3Tree& tree, const TileShardConfig& cfg) {
         int ver = 0;
         ncclGetVersion(&ver);
         transport_ = "RCCL " + std::to_string(ver) + ", " + std::to_string(n_) +
-                     (n_ == 1 ? " rank (self send/recv)" : " ranks, grouped send/recv to the root");
+                     (n_ == 1 ? " rank (self send/recv)" : " ranks, grouped send/recv to the root") +
+                     (n_ > 1 ? ", " + p2p_note_ : "");
     } else {
         transport_ = "REHEARSAL: " + std::to_string(n_) + " ranks share device " +
                      std::to_string(device_[0]) + ", tiles move with hipMemcpyAsync (no RCCL)";

@@ -29,29 +29,30 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-// Scheduling knobs of the persistent kernel (env VR_MARCH_MAX / VR_REFILL_MIN /
-// VR_WAVES_PER_CU at first use, or vr_set_tuning).  They never change results.
+// Scheduling / layout knobs.  They never change results.  Every tree carries its OWN copy
+// (vr_tree_set_tuning), taken at upload from the process defaults below; the defaults come from
+// the environment (VR_MARCH_MAX, VR_REFILL_MIN, VR_WAVES_PER_CU, ... read once) and
+// vr_set_tuning, which only affects trees uploaded afterwards and is serialised by a mutex.
 struct Tuning {
     int march_max = 16;
     int refill_min = 24;
     int waves_per_cu = 0;   // 0: what the kernel flavour fits (vr_kernels.hip waves_per_cu<>)
-    int shade_min = 48;
     int frame_group = 0;   // poses per ray-order group (0 = all poses of the launch, 1 = frame-major)
     int super_block = 1;   // 8x8 blocks per super-block edge in the ray order
     int records_nt = -1;   // record stream non-temporal: -1 = by lookup-structure size, 0 / 1 = forced
     int xcd_queues = 1;
     int chunk_max = 4096;
-    int top_levels = 0;    // lookup structure of trees uploaded from now on (vr_kernels.hip); 0 = auto
+    int top_levels = 0;    // lookup structure built at upload (vr_kernels.hip); 0 = auto
     int brick_levels = 3;
     int split = -1;        // march / shade on separate waves: -1 = where it measures faster, 0 / 1 = forced
 };
-Tuning& tuning() {
+std::mutex g_tuning_mutex;
+Tuning& default_tuning_locked() {  // call with g_tuning_mutex held
     static Tuning tn = [] {
         Tuning x;
         if (const char* e = getenv("VR_MARCH_MAX")) x.march_max = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_REFILL_MIN")) x.refill_min = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_WAVES_PER_CU")) x.waves_per_cu = atoi(e) < 0 ? 0 : atoi(e);
-        if (const char* e = getenv("VR_SHADE_MIN")) x.shade_min = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_FRAME_GROUP")) x.frame_group = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("VR_SUPER_BLOCK")) x.super_block = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_RECORDS_NT")) x.records_nt = atoi(e);
@@ -63,6 +64,25 @@ Tuning& tuning() {
         return x;
     }();
     return tn;
+}
+Tuning default_tuning() {
+    std::lock_guard<std::mutex> g(g_tuning_mutex);
+    return default_tuning_locked();
+}
+bool set_tuning_key(Tuning& tn, const char* key, int value) {
+    if (!strcmp(key, "march_max")) tn.march_max = value < 1 ? 1 : value;
+    else if (!strcmp(key, "refill_min")) tn.refill_min = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (!strcmp(key, "waves_per_cu")) tn.waves_per_cu = value < 0 ? 0 : (value > 64 ? 64 : value);
+    else if (!strcmp(key, "frame_group")) tn.frame_group = value < 0 ? 0 : value;
+    else if (!strcmp(key, "super_block")) tn.super_block = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (!strcmp(key, "records_nt")) tn.records_nt = value < 0 ? -1 : (value != 0);
+    else if (!strcmp(key, "xcd_queues")) tn.xcd_queues = value != 0;
+    else if (!strcmp(key, "chunk_max")) tn.chunk_max = value < 64 ? 64 : (value & ~63);
+    else if (!strcmp(key, "top_levels")) tn.top_levels = value;
+    else if (!strcmp(key, "brick_levels")) tn.brick_levels = value;
+    else if (!strcmp(key, "split")) tn.split = value < 0 ? -1 : (value != 0);
+    else return false;
+    return true;
 }
 
 #define HIP_TRY(expr)                                                                       \
@@ -135,7 +155,8 @@ struct VrTreeOpaque {
     uint32_t* slot_heads = nullptr;        // kLaunchSlots x kSlotWords
     LaunchSlot slots[kLaunchSlots];
     unsigned launch_seq = 0;
-    std::mutex launch_mutex;  // slot bookkeeping + enqueue order of one launch
+    std::mutex launch_mutex;  // slot bookkeeping + enqueue order of one launch; guards `tn`
+    Tuning tn;                // this tree's knobs (vr_tree_set_tuning)
     int n_cus = 256;
     VrTreeDesc desc{};  // pointers cleared; scalars kept
     int32_t max_depth = 0;
@@ -241,6 +262,103 @@ std::vector<int32_t> node_permutation(const int32_t* child, int64_t cap, int N3,
     for (int64_t i = 0; i < cap; ++i)
         if (perm[(size_t)i] < 0) perm[(size_t)i] = next++;
     return perm;
+}
+
+// ---------------------------------------------------------------------------
+// Host -> device copies of the tree arrays at link speed.  hipMemcpy from pageable memory
+// stages through ONE thread's memcpy (~9 GB/s measured: 1.67 GB in 0.19 s); here kCopyWorkers
+// threads each stream their share of the chunks through two pinned slots of their own:
+// memcpy into slot (i & 1) while the DMA of the previous chunk drains slot (i & 1) ^ 1.  No
+// coordination between the workers; the pinned slots are kept in a process-wide free list so
+// that only the first upload allocates them.  Anything small, or any failure to set the
+// pipeline up, falls back to the plain blocking copy.
+// ---------------------------------------------------------------------------
+constexpr size_t kCopyChunk = 4u << 20;
+constexpr int kCopyWorkersMax = 8;
+
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<void*> free_slots;
+    void* take() {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (!free_slots.empty()) {
+                void* p = free_slots.back();
+                free_slots.pop_back();
+                return p;
+            }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, kCopyChunk, hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        return p;
+    }
+    void give(void* p) {
+        std::lock_guard<std::mutex> g(mu);
+        free_slots.push_back(p);
+    }
+};
+PinnedPool& pinned_pool() {
+    static PinnedPool* pool = new PinnedPool();  // never destroyed: no HIP calls at exit
+    return *pool;
+}
+
+hipError_t staged_h2d(void* dst, const void* src, size_t bytes, int device) {
+    const size_t n_chunks = (bytes + kCopyChunk - 1) / kCopyChunk;
+    unsigned hw = std::thread::hardware_concurrency();
+    int workers = hw >= 16 ? kCopyWorkersMax : (hw >= 4 ? (int)hw / 2 : 1);
+    if ((size_t)workers > n_chunks) workers = (int)n_chunks;
+    if (bytes < (32u << 20) || workers < 2) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    std::atomic<int> failed{0};
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        void* slot[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        hipStream_t st = nullptr;
+        bool ok = hipSetDevice(device) == hipSuccess &&
+                  hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i) {
+            slot[i] = pinned_pool().take();
+            ok = slot[i] != nullptr &&
+                 hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+        }
+        bool used[2] = {false, false};
+        // chunks are claimed dynamically (a worker that was scheduled late does not hold the others up)
+        for (int k = 0; ok; k ^= 1) {
+            const size_t c = next.fetch_add(1);
+            if (c >= n_chunks) break;
+            const size_t off = c * kCopyChunk;
+            const size_t len = bytes - off < kCopyChunk ? bytes - off : kCopyChunk;
+            if (used[k]) ok = hipEventSynchronize(ev[k]) == hipSuccess;  // the slot's last DMA is done
+            if (!ok) break;
+            memcpy(slot[k], static_cast<const char*>(src) + off, len);
+            ok = hipMemcpyAsync(static_cast<char*>(dst) + off, slot[k], len, hipMemcpyHostToDevice,
+                                st) == hipSuccess &&
+                 hipEventRecord(ev[k], st) == hipSuccess;
+            used[k] = true;
+        }
+        if (st) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
+        if (!ok) failed.store(1);
+        for (int i = 0; i < 2; ++i) {
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            if (slot[i]) pinned_pool().give(slot[i]);
+        }
+        if (st) (void)hipStreamDestroy(st);
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (int w = 1; w < workers; ++w) pool.emplace_back(work);
+    } catch (...) {  // could not start (all) helpers: this thread copies what is left
+    }
+    work();
+    for (auto& t : pool) t.join();
+    if (failed.load()) {
+        (void)hipGetLastError();
+        return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);  // plain copy of everything
+    }
+    return hipSuccess;
 }
 
 // same rounding sequence as the oracle's norm3 (strict / fma)
@@ -357,7 +475,7 @@ static int check_quant(const VrTreeDesc* d, const VrQuantDesc* q) {
 // Stages the codebook arrays on the device (unless they are there already) and decodes
 // them into `d_data` (flat reference layout, n_slots * data_dim halfs, device memory).
 static hipError_t decode_quant_on_device(const VrTreeDesc* d, const VrQuantDesc* q, size_t n_slots,
-                                         uint16_t* d_data) {
+                                         uint16_t* d_data, int device) {
     const size_t sz_colors = (size_t)q->n_quant * 65536 * 3 * sizeof(uint16_t);
     const size_t sz_map = (size_t)q->n_quant * n_slots * sizeof(uint16_t);
     const size_t sz_sigma = n_slots * sizeof(uint16_t);
@@ -374,7 +492,7 @@ static hipError_t decode_quant_on_device(const VrTreeDesc* d, const VrQuantDesc*
             continue;
         }
         e = hipMalloc(&tmp[i], sz[i]);
-        if (e == hipSuccess) e = hipMemcpy(tmp[i], src[i], sz[i], hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = staged_h2d(tmp[i], src[i], sz[i], device);
         dev[i] = tmp[i];
     }
     if (e == hipSuccess)
@@ -434,7 +552,7 @@ static hipError_t alloc_launch_scratch(VrTreeOpaque* t) {
     return e;
 }
 
-static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out) {
+static int upload_body(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out) {
     if (!d || !out) return fail(VR_ERR_INVALID_ARGUMENT, "desc/out is NULL");
     *out = nullptr;
     if (int rc = check_tree_desc(d, q == nullptr)) return rc;
@@ -468,14 +586,14 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
         hipError_t e = hipSetDevice(device);
         if (d->memory != 1) {
             if (e == hipSuccess) e = hipMalloc((void**)&d_child, child_sz);
-            if (e == hipSuccess) e = hipMemcpy(d_child, d->child, child_sz, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = staged_h2d(d_child, d->child, child_sz, device);
         }
         if (q) {  // quantised file: only the codebook arrays cross PCIe, the decode runs on the device
             if (e == hipSuccess) e = hipMalloc((void**)&d_data, data_sz);
-            if (e == hipSuccess) e = decode_quant_on_device(d, q, n_slots, d_data);
+            if (e == hipSuccess) e = decode_quant_on_device(d, q, n_slots, d_data, device);
         } else if (d->memory != 1) {
             if (e == hipSuccess) e = hipMalloc((void**)&d_data, data_sz);
-            if (e == hipSuccess) e = hipMemcpy(d_data, d->data, data_sz, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = staged_h2d(d_data, d->data, data_sz, device);
         }
         e_copy = e;
     });
@@ -504,8 +622,8 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     // Lookup structure (N == 2 fast path): leaves must sit within 24 levels (exact integer
     // digits of a binary32 coordinate) and node*8+slot byte offsets must fit 32 bits.
     int G0 = 0, BL = 0;
+    const Tuning tn = default_tuning();  // the new tree's own copy from here on
     if (d->N == 2 && max_depth <= 23 && d->capacity < (1ll << 27)) {
-        const Tuning& tn = tuning();
         // auto: top grid + brick reach the deepest leaf (depth max_depth + 1) without a child-word
         // walk where a top grid of <= 256^3 cells allows it -- 64^3 (2 MB) for lego-class trees of
         // 9 levels, 128^3 for 10 (measured: C1 0.269 ms at (6,3) against 0.301 at (5,3); C3 0.790
@@ -529,6 +647,7 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     t->desc.extra = nullptr;
     t->max_depth = max_depth;
     t->device = device;
+    t->tn = tn;
     // new node numbering (host walk) while the copies are still in flight
     std::vector<int32_t> brick_roots;
     const std::vector<int32_t> perm =
@@ -606,6 +725,20 @@ static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     return VR_OK;
 }
 
+// The host side of an upload allocates (level / permutation vectors) and starts threads: nothing
+// of that may leave through the C boundary as an exception.
+static int upload_impl(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out) {
+    try {
+        return upload_body(d, q, out);
+    } catch (const std::bad_alloc&) {
+        if (out) *out = nullptr;
+        return fail(VR_ERR_OUT_OF_MEMORY, "tree upload: host allocation failed");
+    } catch (const std::exception& e) {  // std::system_error of a thread that could not start
+        if (out) *out = nullptr;
+        return fail(VR_ERR_OUT_OF_MEMORY, "tree upload: %s", e.what());
+    }
+}
+
 int vr_tree_upload(const VrTreeDesc* d, vr_tree_t* out) { return upload_impl(d, nullptr, out); }
 
 int vr_tree_upload_quantized(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out) {
@@ -623,7 +756,9 @@ int vr_decode_quantized(const VrTreeDesc* d, const VrQuantDesc* q, uint16_t* dat
     uint16_t* d_data = data_out;
     hipError_t e = hipSuccess;
     if (d->memory != 1) e = hipMalloc((void**)&d_data, data_sz);
-    if (e == hipSuccess) e = decode_quant_on_device(d, q, n_slots, d_data);
+    int device = 0;
+    if (e == hipSuccess) e = hipGetDevice(&device);
+    if (e == hipSuccess) e = decode_quant_on_device(d, q, n_slots, d_data, device);
     if (e == hipSuccess && d->memory != 1)
         e = hipMemcpy(data_out, d_data, data_sz, hipMemcpyDeviceToHost);
     if (d->memory != 1 && d_data) (void)hipFree(d_data);
@@ -640,7 +775,10 @@ int vr_tree_clone(vr_tree_t src, int device, vr_tree_t* out) {
     HIP_TRY(hipGetDeviceCount(&n_dev));
     if (device < 0 || device >= n_dev)
         return fail(VR_ERR_INVALID_ARGUMENT, "device %d outside [0,%d)", device, n_dev);
-    {   // the source may still be uploading / rendering on its own device
+    // the source may still be rendering on its own device; no launch may be enqueued on it (nor
+    // its bitmaps / slots change) while its arrays are read
+    std::lock_guard<std::mutex> src_lock(src->launch_mutex);
+    {
         DeviceGuard g(src->device);
         HIP_TRY(hipDeviceSynchronize());
     }
@@ -651,6 +789,7 @@ int vr_tree_clone(vr_tree_t src, int device, vr_tree_t* out) {
     t->desc = src->desc;
     t->max_depth = src->max_depth;
     t->leaf_stride_h = src->leaf_stride_h;
+    t->tn = src->tn;
     t->top_levels = src->top_levels;
     t->brick_levels = src->brick_levels;
     t->n_bricks = src->n_bricks;
@@ -658,6 +797,20 @@ int vr_tree_clone(vr_tree_t src, int device, vr_tree_t* out) {
     for (int i = 0; i < 4; ++i) t->array_bytes[i] = src->array_bytes[i];
     // the re-laid-out arrays travel device to device (over xGMI between two GPUs of a node):
     // no second pass over PCIe, no second re-layout
+    // direct peer access (xGMI / PCIe P2P) when the two devices have it: hipMemcpyPeer then moves
+    // the arrays device to device; without it the runtime stages them through host memory
+    // (still correct, ~10x slower) -- vr_last_error() keeps a note either way
+    bool p2p = true;
+    if (src->device != device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device, src->device) != hipSuccess) can = 0;
+        p2p = can != 0;
+        if (p2p) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) p2p = false;
+        }
+        (void)hipGetLastError();
+    }
     void** dst[4] = {(void**)&t->leaves, (void**)&t->nodes, (void**)&t->top, (void**)&t->bricks};
     const void* from[4] = {src->leaves, src->nodes, src->top, src->bricks};
     hipError_t e = hipSuccess;
@@ -677,8 +830,14 @@ int vr_tree_clone(vr_tree_t src, int device, vr_tree_t* out) {
     if (e != hipSuccess) {
         vr_tree_free(t);
         return fail(e == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP,
-                    "tree clone to device %d failed: %s", device, hipGetErrorString(e));
+                    "tree clone from device %d to device %d failed: %s%s", src->device, device,
+                    hipGetErrorString(e),
+                    p2p ? "" : " (the devices have NO peer access: check `rocm-smi --showtopo`, "
+                               "IOMMU / ACS settings and HSA_ENABLE_IPC_MODE_LEGACY=0)");
     }
+    if (!p2p)
+        (void)fail(VR_OK, "note: devices %d and %d have no peer access; the clone was staged "
+                          "through host memory", src->device, device);
     *out = t;
     return VR_OK;
 }
@@ -773,20 +932,19 @@ int64_t vr_compact_bytes(int width, int height, int tile_w, int tile_h, int worl
 
 int vr_set_tuning(const char* key, int value) {
     if (!key) return fail(VR_ERR_INVALID_ARGUMENT, "key is NULL");
-    Tuning& tn = tuning();
-    if (!strcmp(key, "march_max")) tn.march_max = value < 1 ? 1 : value;
-    else if (!strcmp(key, "refill_min")) tn.refill_min = value < 1 ? 1 : (value > 64 ? 64 : value);
-    else if (!strcmp(key, "waves_per_cu")) tn.waves_per_cu = value < 0 ? 0 : (value > 64 ? 64 : value);
-    else if (!strcmp(key, "shade_min")) tn.shade_min = value < 1 ? 1 : (value > 64 ? 64 : value);
-    else if (!strcmp(key, "frame_group")) tn.frame_group = value < 0 ? 0 : value;
-    else if (!strcmp(key, "super_block")) tn.super_block = value < 1 ? 1 : (value > 64 ? 64 : value);
-    else if (!strcmp(key, "records_nt")) tn.records_nt = value < 0 ? -1 : (value != 0);
-    else if (!strcmp(key, "xcd_queues")) tn.xcd_queues = value != 0;
-    else if (!strcmp(key, "chunk_max")) tn.chunk_max = value < 64 ? 64 : (value & ~63);
-    else if (!strcmp(key, "top_levels")) tn.top_levels = value;
-    else if (!strcmp(key, "brick_levels")) tn.brick_levels = value;
-    else if (!strcmp(key, "split")) tn.split = value < 0 ? -1 : (value != 0);
-    else return fail(VR_ERR_INVALID_ARGUMENT, "unknown tuning key '%s'", key);
+    std::lock_guard<std::mutex> g(g_tuning_mutex);
+    if (!set_tuning_key(default_tuning_locked(), key, value))
+        return fail(VR_ERR_INVALID_ARGUMENT, "unknown tuning key '%s'", key);
+    return VR_OK;
+}
+
+int vr_tree_set_tuning(vr_tree_t t, const char* key, int value) {
+    if (!t || !key) return fail(VR_ERR_INVALID_ARGUMENT, "tree/key is NULL");
+    if (!strcmp(key, "top_levels") || !strcmp(key, "brick_levels"))
+        return fail(VR_ERR_INVALID_ARGUMENT, "'%s' is fixed at upload (vr_set_tuning before it)", key);
+    std::lock_guard<std::mutex> g(t->launch_mutex);
+    if (!set_tuning_key(t->tn, key, value))
+        return fail(VR_ERR_INVALID_ARGUMENT, "unknown tuning key '%s'", key);
     return VR_OK;
 }
 
@@ -805,6 +963,7 @@ static size_t touch_words(uint64_t array_bytes) {  // one bit per 128-byte line
 int vr_touch_enable(vr_tree_t t, int enable) {
     if (!t) return fail(VR_ERR_INVALID_ARGUMENT, "tree is NULL");
     DeviceGuard guard(t->device);
+    std::lock_guard<std::mutex> lock(t->launch_mutex);  // no launch is being enqueued meanwhile
     HIP_TRY(hipDeviceSynchronize());  // no launch may be using the bitmaps while they change
     for (int i = 0; i < 4; ++i) {
         if (t->touch[i]) {
@@ -825,6 +984,7 @@ int vr_touch_count(vr_tree_t t, uint64_t out[4], int reset) {
     if (!t || !out) return fail(VR_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!t->touch_out) return fail(VR_ERR_INVALID_ARGUMENT, "vr_touch_enable(tree, 1) first");
     DeviceGuard guard(t->device);
+    std::lock_guard<std::mutex> lock(t->launch_mutex);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(t->touch_out, 0, 4 * sizeof(unsigned long long)));
     for (int i = 0; i < 4; ++i) {
@@ -939,19 +1099,18 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.layout = f->layout;
     k.instrumented = instrumented ? 1 : 0;
     k.any_accum = any_accum ? 1 : 0;
-    const Tuning& tn = tuning();
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> guard(t->launch_mutex);
+    const Tuning& tn = t->tn;
     // lookup structure (top + bricks) beyond 4x the aggregate L2 (8 x 4 MiB on MI355X): the record
     // stream would keep evicting it -- see the DMA loads in vr_kernels.hip
     k.records_nt = tn.records_nt >= 0 ? tn.records_nt
                                       : (t->array_bytes[2] + t->array_bytes[3] > (128ull << 20));
     k.march_max = tn.march_max;
     k.refill_min = tn.refill_min;
-    k.shade_min = tn.shade_min;
     k.frame_group = tn.frame_group < 1 || tn.frame_group > n_frames ? n_frames : tn.frame_group;
     k.super_block = tn.super_block;
     // launch slot: per-launch scratch in device memory (ring, see LaunchSlot)
-    hipStream_t hs = static_cast<hipStream_t>(stream);
-    std::lock_guard<std::mutex> guard(t->launch_mutex);
     const size_t need = ray_buffer_bytes(k.total_rays, basis_words_of(t));
     unsigned slot = kLaunchSlots;
     for (int want_fit = 1; want_fit >= 0 && slot == kLaunchSlots; --want_fit) {
@@ -996,6 +1155,21 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.ray_buf = k.ray_buf_rw;
     // whoever used this slot last (any stream) must have finished before its scratch is rewritten
     if (ls.used) HIP_TRY(hipStreamWaitEvent(hs, ls.done, 0));
+    // From here on kernels of this launch may be in the stream: whatever happens below (a later
+    // enqueue failing), the slot's event is recorded behind them and the slot is marked used, so
+    // that the next user of the slot -- any stream -- waits for whatever did get enqueued.
+    struct SlotSeal {
+        LaunchSlot& ls;
+        hipStream_t hs;
+        ~SlotSeal() {
+            if (hipEventRecord(ls.done, hs) == hipSuccess) {
+                ls.used = true;
+                ls.last_stream = hs;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    } seal{ls, hs};
     k.probe_coeffs = t->probe_buf + (size_t)slot * (size_t)t->desc.data_dim;
     if (k.enable_probe)  // launch_renderer's pre-kernel, volrend.cu:202-209
         HIP_TRY(vr::launch_probe(k, opt->probe, const_cast<float*>(k.probe_coeffs), hs));
@@ -1015,31 +1189,43 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
         }
         HIP_TRY(vr::launch_prepare(k, tbl, hs));
     }
-    // SH25 keeps the fused kernel: its shade state does not fit the split kernel's register budget
-    const int split = tn.split >= 0 ? tn.split : (t->desc.basis_dim != 25);
+    // Kernel organisation of the FAST flavours (vr_kernels.hip): ONE frame per launch -- the
+    // reference's launch_renderer contract -- is a latency-bound job (about one ray per resident
+    // lane, the frame takes as long as its longest ray): there the split kernel (march and shade
+    // on separate waves, 8 waves per SIMD, rays retired without waiting for their colour) is
+    // 10 % faster (C1 0.56 against 0.63 ms, C3 1.20 against 1.33).  Batches are throughput-bound
+    // and the split kernel executes ~30 % more instructions for the same work: fused wins from 2
+    // frames on (profiles/r03_split_vs_fused.jsonl).  SH25's shade state does not fit the split
+    // kernel's register budget at all.
+    const int split = tn.split >= 0 ? tn.split : (n_frames == 1 && t->desc.basis_dim != 25);
     HIP_TRY(vr::launch_render(k, f->fp_mode, t->n_cus, tn.waves_per_cu, split, hs));
-    HIP_TRY(hipEventRecord(ls.done, hs));
-    ls.used = true;
-    ls.last_stream = hs;
-    return VR_OK;
+    return VR_OK;  // (`seal` records the slot's event)
 }
 
-int vr_reserve(vr_tree_t t, int width, int height, int n_frames) {
+int vr_reserve_tiles(vr_tree_t t, int width, int height, int n_frames, int tile_w, int tile_h,
+                     int world, int n_slots) {
     if (!t) return fail(VR_ERR_INVALID_ARGUMENT, "tree is NULL");
     if (width < 1 || height < 1 || width > 65535 || height > 65535 || n_frames < 1 ||
         n_frames > VR_MAX_BATCH)
         return fail(VR_ERR_INVALID_ARGUMENT, "vr_reserve(%d x %d, %d frames) out of range", width,
                     height, n_frames);
-    // whole frames (world = 1), rounded up to 8x8 wave blocks like tile_geometry does
-    const int64_t total = (int64_t)((width + 7) / 8) * ((height + 7) / 8) * 64 * n_frames;
+    if (n_slots < 1 || n_slots > (int)kLaunchSlots)
+        return fail(VR_ERR_INVALID_ARGUMENT, "n_slots=%d outside [1,%u]", n_slots, kLaunchSlots);
+    if (world < 1) world = 1;
+    // exactly the ray count vr_render_batch computes: the rank's tiles, rounded up to WHOLE tiles
+    // (rank 0 holds the most)
+    int tw, th, tx, ty;
+    if (int rc = tile_geometry(width, height, tile_w, tile_h, &tw, &th, &tx, &ty)) return rc;
+    const int64_t n_tiles = (int64_t)tx * ty;
+    const int64_t local_tiles = (n_tiles + world - 1) / world;
+    const int64_t total = local_tiles * (tw / 8) * (th / 8) * 64 * n_frames;
     if (total >= (1ll << 30))
         return fail(VR_ERR_INVALID_ARGUMENT, "batch of %lld rays exceeds the 2^30-ray queue",
                     (long long)total);
     const size_t need = ray_buffer_bytes((uint32_t)total, basis_words_of(t));
     DeviceGuard device_guard(t->device);
     std::lock_guard<std::mutex> guard(t->launch_mutex);
-    // two slots: what a render loop on one stream (one slot) or on two alternating streams needs
-    for (unsigned i = 0; i < 2; ++i) {
+    for (int i = 0; i < n_slots; ++i) {
         LaunchSlot& ls = t->slots[i];
         if (ls.ray_bytes >= need) continue;
         if (ls.rays) {
@@ -1052,6 +1238,12 @@ int vr_reserve(vr_tree_t t, int width, int height, int n_frames) {
         ls.ray_bytes = need;
     }
     return VR_OK;
+}
+
+// two slots of whole frames: what a render loop on one stream (one slot) or on two alternating
+// streams needs
+int vr_reserve(vr_tree_t t, int width, int height, int n_frames) {
+    return vr_reserve_tiles(t, width, height, n_frames, 0, 0, 1, 2);
 }
 
 int vr_tree_status(vr_tree_t t, uint32_t* status, int reset) {

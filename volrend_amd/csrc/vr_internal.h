@@ -91,7 +91,6 @@ struct KParams {
     int32_t basis_words;         // basis_fn words per ray in ray_buf (0 for RGBA)
     int32_t refill_min;          // refill once this many lanes are idle
     int32_t march_max;           // march steps per lane between two shade checks
-    int32_t shade_min;           // shade once this many lanes have queued colour work
     int32_t instrumented;        // any frame carries counters -> FULL flavour
     int32_t any_accum;           // some frame of the launch asks for its fp32 accumulators
     int32_t records_nt;          // record DMA loads carry the non-temporal hint (large lookup structures)

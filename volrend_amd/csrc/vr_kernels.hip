@@ -19,13 +19,133 @@ namespace vr {
 namespace {
 
 constexpr int kWave = 64;
+// ===========================================================================
+// EXPERIMENT HOOKS.  Everything between these two fences exists for timing experiments and
+// profiling builds (tools/*.sh, profiles/*): -DVR_ABLATE=n removes work ON PURPOSE (wrong
+// pictures, never shipped -- the build script refuses to install such a library as the
+// product), -DVR_TIMELINE=n adds shader-clock reads around the phases.  The product build
+// (both 0) gets the first branch of each #if: plain expressions and empty statements.  The
+// kernels below only use the VR_EXP_* / TL_* names.
+// ===========================================================================
 #ifndef VR_ABLATE
-#define VR_ABLATE 0  // != 0: timing experiments that break the results (never shipped)
+#define VR_ABLATE 0
 #endif
 #ifndef VR_TIMELINE
-#define VR_TIMELINE 0  // 1: the FAST flavour accumulates per-phase shader-clock cycles into
-                       // sched_stats (profiling builds only; costs a few s_memtime per iteration)
+#define VR_TIMELINE 0  // 1: per-phase cycle sums into sched_stats; 2: march-round breakdown (split kernel)
 #endif
+#if VR_ABLATE == 0
+#define VR_EXP_RECORD_CHUNK(v, j, leaf) ((v)[j])   // 16-byte chunk j of a record (register path)
+#define VR_EXP_RECORD_LEAF(leaf) (leaf)            // the record an item names (DMA path)
+#define VR_EXP_RECORD_DMA 1                        // record DMAs are issued
+#define VR_EXP_FUSED_COLOUR 1                      // fused kernel: hit samples queue colour work
+#define VR_EXP_SPLIT_COLOUR 1                      // split kernel: the shade wave does its colour work
+#else
+#define VR_EXP_RECORD_CHUNK(v, j, leaf) \
+    (VR_ABLATE == 1 ? (v)[0] : VR_ABLATE == 2 ? make_uint4((leaf) + (j), (leaf), (leaf), (leaf)) : (v)[j])
+#define VR_EXP_RECORD_LEAF(leaf) (VR_ABLATE == 5 ? ((leaf) & 0x3FFu) : (leaf))  // 5: a 128 KB window
+#define VR_EXP_RECORD_DMA (VR_ABLATE != 4)         // 4: no record fetch at all
+#define VR_EXP_FUSED_COLOUR (VR_ABLATE != 6)       // 6: fused kernel marches without colour work
+#define VR_EXP_SPLIT_COLOUR (VR_ABLATE != 7)       // 7: the shade wave only consumes its items
+#endif
+#if VR_TIMELINE
+#define TL_MARK() (tl_mark = __builtin_readcyclecounter())
+#define TL_ADD(v) do { const unsigned long long n_ = __builtin_readcyclecounter(); \
+                       (v) += n_ - tl_mark; tl_mark = n_; } while (0)
+#else
+#define TL_MARK() ((void)0)
+#define TL_ADD(v) ((void)0)
+#endif
+#if VR_TIMELINE == 2
+#define TL2_MARK() (tl2_mark = __builtin_readcyclecounter())
+#define TL2_ADD(v) do { const unsigned long long n_ = __builtin_readcyclecounter(); \
+                        (v) += n_ - tl2_mark; tl2_mark = n_; } while (0)
+#define TL2_COUNT(go_) do { tl2_rounds++; tl2_lanes += (unsigned long long)__builtin_popcountll( \
+                            __builtin_amdgcn_ballot_w64(go_)); } while (0)
+#else
+#define TL2_MARK() ((void)0)
+#define TL2_ADD(v) ((void)0)
+#define TL2_COUNT(go_) ((void)0)
+#endif
+// declarations / dumps of the cycle tallies (sched_stats words: see tools/quick_ab.py, bench.py)
+#if VR_TIMELINE
+#define TL_DECL_FUSED()                                                                          \
+    unsigned long long tl_refill = 0, tl_march = 0, tl_shade_load = 0, tl_shade_math = 0,        \
+                       tl_shade_acc = 0, tl_total0 = __builtin_readcyclecounter(), tl_mark = 0,  \
+                       tl_drained = 0 /* when this wave found the ray queue empty */
+#define TL_QUEUE_DRY() (tl_drained = __builtin_readcyclecounter())
+#define TL_DUMP_FUSED()                                                                           \
+    do {                                                                                          \
+        if (!COUNT && p.sched_stats && lane == 0) {                                               \
+            atomicAdd(&p.sched_stats[0], tl_refill);                                              \
+            atomicAdd(&p.sched_stats[1], tl_march);                                               \
+            atomicAdd(&p.sched_stats[2], tl_shade_load);                                          \
+            atomicAdd(&p.sched_stats[3], tl_shade_math);                                          \
+            atomicAdd(&p.sched_stats[4], tl_shade_acc);                                           \
+            atomicAdd(&p.sched_stats[5], (unsigned long long)__builtin_readcyclecounter() - tl_total0); \
+            atomicAdd(&p.sched_stats[6], 1ull);                                                   \
+            /* the wave's tail: from the moment the queue was empty to its last retired ray */    \
+            atomicAdd(&p.sched_stats[7], (unsigned long long)__builtin_readcyclecounter() - tl_drained); \
+        }                                                                                         \
+    } while (0)
+#define TL_DECL_MARCH()                                                                           \
+    unsigned long long tl_mark = __builtin_readcyclecounter(), tl_m_refill = 0, tl_m_march = 0,   \
+                       tl_m_stall = 0, tl2_mark = 0, tl2_peek = 0, tl2_query = 0, tl2_push = 0,   \
+                       tl2_rounds = 0, tl2_lanes = 0;                                             \
+    (void)tl2_mark, (void)tl2_peek, (void)tl2_query, (void)tl2_push, (void)tl2_rounds, (void)tl2_lanes
+#define TL_DECL_SHADE()                                                                           \
+    unsigned long long tl_mark = __builtin_readcyclecounter(), tl_s_idle = 0, tl_s_event = 0,     \
+                       tl_s_dma = 0, tl_s_math = 0, tl2_chunks = 0, tl2_items = 0
+#define TL_SHADE_CHUNK(n_) do { tl2_chunks++; tl2_items += (unsigned long long)(n_); } while (0)
+#if VR_TIMELINE == 2
+#define TL_DUMP_MARCH()                                                                           \
+    do {                                                                                          \
+        if (p.sched_stats && lane == 0) {                                                         \
+            atomicAdd(&p.sched_stats[0], tl2_peek);                                               \
+            atomicAdd(&p.sched_stats[1], tl2_query);                                              \
+            atomicAdd(&p.sched_stats[2], tl2_push);                                               \
+            atomicAdd(&p.sched_stats[3], tl2_rounds);                                             \
+            atomicAdd(&p.sched_stats[4], tl2_lanes);                                              \
+            atomicAdd(&p.sched_stats[7], 1ull);                                                   \
+        }                                                                                         \
+    } while (0)
+#define TL_DUMP_SHADE()                                                                           \
+    do {                                                                                          \
+        if (p.sched_stats && lane == 0) {                                                         \
+            atomicAdd(&p.sched_stats[5], tl2_chunks);                                             \
+            atomicAdd(&p.sched_stats[6], tl2_items);                                              \
+        }                                                                                         \
+    } while (0)
+#else
+#define TL_DUMP_MARCH()                                                                           \
+    do {                                                                                          \
+        if (p.sched_stats && lane == 0) {                                                         \
+            atomicAdd(&p.sched_stats[0], tl_m_refill);                                            \
+            atomicAdd(&p.sched_stats[1], tl_m_march);                                             \
+            atomicAdd(&p.sched_stats[2], tl_m_stall);                                             \
+            atomicAdd(&p.sched_stats[7], 1ull);                                                   \
+        }                                                                                         \
+    } while (0)
+#define TL_DUMP_SHADE()                                                                           \
+    do {                                                                                          \
+        if (p.sched_stats && lane == 0) {                                                         \
+            atomicAdd(&p.sched_stats[3], tl_s_idle);                                              \
+            atomicAdd(&p.sched_stats[4], tl_s_event);                                             \
+            atomicAdd(&p.sched_stats[5], tl_s_dma);                                               \
+            atomicAdd(&p.sched_stats[6], tl_s_math);                                              \
+        }                                                                                         \
+    } while (0)
+#endif
+#else
+#define TL_DECL_FUSED() ((void)0)
+#define TL_QUEUE_DRY() ((void)0)
+#define TL_DUMP_FUSED() ((void)0)
+#define TL_DECL_MARCH() ((void)0)
+#define TL_DECL_SHADE() ((void)0)
+#define TL_SHADE_CHUNK(n_) ((void)0)
+#define TL_DUMP_MARCH() ((void)0)
+#define TL_DUMP_SHADE() ((void)0)
+#endif
+// ========================= end of the experiment hooks =====================
 #ifndef VR_MIN_WAVES_PER_EU
 #define VR_MIN_WAVES_PER_EU 8  // cap on the per-flavour register bounds (experiments)
 #endif
@@ -242,8 +362,9 @@ template <bool COUNT = false>
 __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* depth,
                                              uint32_t* word, Cursor& cur) {
     // clamp to [0, 1 - 1e-6] (n3tree_query.hpp:17-19) as ONE v_med3_f32 per axis: identical to
-    // max(min(x, hi), 0) for every non-NaN x (-0 -> +0 included); a NaN position (only a
-    // non-finite pose can produce one) is not defined by the reference either
+    // max(min(x, hi), 0) for every non-NaN x (-0 -> +0 included).  Deviation, non-finite poses
+    // only: the reference's max(min(NaN, hi), 0) is `hi` (fminf / fmaxf drop the NaN), the
+    // median of (NaN, 0, hi) is 0 -- such a ray samples the other corner of the volume
     const float hi = 1.f - 1e-6f;
     xyz[0] = __builtin_amdgcn_fmed3f(xyz[0], 0.f, hi);
     xyz[1] = __builtin_amdgcn_fmed3f(xyz[1], 0.f, hi);
@@ -360,13 +481,7 @@ __device__ __forceinline__ void load_record(const KParams& p, uint32_t leaf, Rec
         const uint4* v = reinterpret_cast<const uint4*>(base);
 #pragma unroll
         for (int j = 0; j < RecTraits<BASIS>::kDwords / 4; ++j) {
-#if VR_ABLATE == 1   // timing experiment only: one 16-byte load per record instead of all
-            const uint4 q = v[0];
-#elif VR_ABLATE == 2  // timing experiment only: no record load at all
-            const uint4 q = make_uint4(leaf + j, leaf, leaf, leaf);
-#else
-            const uint4 q = v[j];
-#endif
+            const uint4 q = VR_EXP_RECORD_CHUNK(v, j, leaf);
             r.w[4 * j + 0] = q.x;
             r.w[4 * j + 1] = q.y;
             r.w[4 * j + 2] = q.z;
@@ -528,16 +643,14 @@ __device__ __forceinline__ bool wave_any(bool v) { return __builtin_amdgcn_ballo
 // render_kernel: render_kernel + trace_ray of the reference
 // (volrend.cu:78-173, rt_core.cuh:66-196) as a PERSISTENT wave64 kernel.
 //
-//   * The launch covers one or more frames of the same size (a batch of poses);
-//     their rays form one queue: ray id -> (frame, 8x8 pixel block, pixel).
-//   * A fixed number of waves (one 64-thread workgroup each) stays resident.  A wave
-//     takes 64 consecutive ray ids with ONE atomic add on the queue head and sets
-//     them up with all 64 lanes (ray generation is FP64-heavy: never run it on a
-//     few lanes).  Rays that miss the volume are finished on the spot; the rest
-//     are compacted (wave ballot + mbcnt prefix count) into a wave-private LDS
-//     ray cache.  Whenever >= refill_min lanes are idle, the k-th idle lane takes
-//     cache entry next + k.  Terminated rays are replaced in place -- live rays
-//     never move between lanes.
+//   * The launch covers one or more frames of the same size (a batch of poses).  Ray
+//     generation is a kernel of its own (raygen_kernel below: one lane per pixel at full
+//     occupancy, FP64-heavy); the rays that enter the volume sit compacted in the ray buffer,
+//     ray id -> (frame, 8x8 pixel block, pixel) by locate().
+//   * A fixed number of waves (one 64-thread workgroup each) stays resident.  A wave owns a
+//     chunk of consecutive ray ids (one atomic add on a queue head per chunk); whenever
+//     >= refill_min lanes are idle, the k-th idle lane loads ray chunk_next + k from the
+//     buffer.  Terminated rays are replaced in place -- live rays never move between lanes.
 //   * The colour of a sample never feeds back into the march (only the
 //     attenuation does), so colour evaluation is decoupled from the ray that
 //     produced it.  The wave alternates two phases, each with most lanes busy:
@@ -545,11 +658,13 @@ __device__ __forceinline__ bool wave_any(bool v) { return __builtin_amdgcn_ballo
 //               samples with sigma > sigma_thresh append a (leaf, weight, owner)
 //               item to a wave-level LDS ring (ballot + mbcnt compaction);
 //       shade : as soon as 64 items wait, every lane takes ONE item -- whoever
-//               owns it -- fetches the SH record, reads the owner's basis from
-//               LDS and evaluates the colour; then each owner adds the results
+//               owns it -- the SH records arrive by LDS-DMA, the owner's basis through
+//               ds_bpermute; then each owner adds the results
 //               of its own items, oldest first (the reference's order per ray).
 //   * Finished rays composite over the background, quantise and store their
-//     pixel -- retired and refilled in batches of >= refill_min lanes.
+//     pixel -- retired and refilled in batches of >= refill_min lanes, one memory round
+//     trip per batch.
+//   (render_ms_kernel further down runs the same two phases on separate waves.)
 // Per-ray arithmetic and its order are exactly the reference's.
 // ---------------------------------------------------------------------------
 struct Ray {
@@ -807,9 +922,7 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
 //   res   : the three colour contributions of each item of the round (aliases the first
 //           768 bytes of `stage`: every row has been consumed by then)
 // The basis of a lane's ray lives in that lane's registers; the lane that shades one of its
-// items reads it through the LDS crossbar (ds_bpermute).  (Reading it from the ray buffer
-// instead frees 16 VGPRs but costs 37 % frame time: 16 more lines per shade round that the
-// record stream keeps evicting from L2 -- measured, profiles/r02_experiments.md.)
+// items reads it through the LDS crossbar (ds_bpermute).
 // ---------------------------------------------------------------------------
 constexpr int kRayWords = 16;
 // Blocked structure of arrays: the rays are stored in blocks of 64, word k of the 64 rays of a
@@ -837,9 +950,9 @@ struct Stage {
     static constexpr int kVec = kEnabled ? RecTraits<BASIS>::kDwords / 4 : 1;  // V: 2, 4, 6, 10
     static constexpr int kRow = kVec * 16;                            // bytes
     static constexpr int kPerInstr = kWave / kVec;                    // records per DMA instruction
-    // LDS budget: ring (1152 B) + stage <= 6656 B = 24 waves per CU.  SH16 (96-byte rows) shades
-    // VR_SH16_ROWS = 56 items per round in one pass, SH25 (160-byte rows) 64 items in two passes
-    // of 32, the narrower formats 64 items in one pass.
+    // Rows per pass: SH16 (96-byte rows) shades VR_SH16_ROWS = 64 items per round in one pass
+    // (6 KB of rows), SH25 (160-byte rows) 64 items in two passes of 32, the narrower formats 64
+    // items in one pass.
     static constexpr int kPass = !kEnabled ? kWave
                                  : (kRow * kWave <= 5504 ? kWave
                                     : (BASIS == BASIS_16 ? VR_SH16_ROWS : kWave / 2));  // rows per pass
@@ -868,29 +981,25 @@ __device__ __forceinline__ void issue_records(const KParams& p, char* stage, con
         const int rin = k * ST::kPerInstr + lane / ST::kVec;  // record within the pass
         const int item = pass * ST::kPass + rin;
         if (lane < ST::kPerInstr * ST::kVec && rin < ST::kPass && item < n) {
-#if VR_ABLATE == 5   // timing experiment only: every record comes from a 128 KB window
-            const uint32_t leaf = it_leaf[(ring_head + (uint32_t)item) & (RING - 1)] & 0x3FFu;
-#else
-            const uint32_t leaf = it_leaf[(ring_head + (uint32_t)item) & (RING - 1)];
-#endif
+            const uint32_t leaf = VR_EXP_RECORD_LEAF(it_leaf[(ring_head + (uint32_t)item) & (RING - 1)]);
             const char* src = reinterpret_cast<const char*>(p.leaves) +
                               (uint64_t)leaf * (uint32_t)(p.leaf_stride_h * 2) + (lane % ST::kVec) * 16;
-#if VR_ABLATE != 4   // 4 = timing experiment only: no record fetch at all
             // (the LDS address is formed in address space 3: a generic-pointer detour between two
             // casts does not fold when `stage` is not the first LDS object of the kernel)
-            __builtin_amdgcn_global_load_lds(
-                (vr_gptr_t)src,
-                (vr_lptr_t)((__attribute__((address_space(3))) char*)stage + k * ST::kPerInstr * ST::kRow),
-                16, 0, NT ? 2 /* nt */ : 0);
-#endif
+            if (VR_EXP_RECORD_DMA)
+                __builtin_amdgcn_global_load_lds(
+                    (vr_gptr_t)src,
+                    (vr_lptr_t)((__attribute__((address_space(3))) char*)stage + k * ST::kPerInstr * ST::kRow),
+                    16, 0, NT ? 2 /* nt */ : 0);
         }
     }
 }
 
-// Register budget of the production (FAST) flavours, from their natural register use: SH16 <= 80
-// VGPRs (6 waves per SIMD -- with its 6.4 KB of LDS that is 24 waves per CU), SH9 <= 72 (7),
-// SH25 <= 128 (4: it gathers its 25 basis values up front), the small records 8.  The instrumented / lobe / generic flavours keep their
-// wider state in registers at 4 waves per SIMD (3 for SH25: no scratch in any flavour).
+// Register budget of the fused FAST flavours (waves per SIMD), from their natural register use:
+// SH16 96 VGPRs -> VR_SH16_WAVES = 5 (20 waves per CU; 6 needs <= 80 and spills), SH9 <= 80 ->
+// VR_SH9_WAVES = 6, SH25 <= 128 -> 4 (it gathers its 25 basis values up front), the small
+// records 8.  The instrumented / lobe / generic flavours keep their wider state in registers at
+// 4 waves per SIMD (3 for SH25).  No render flavour uses scratch.
 template <int BASIS, int MODE>
 constexpr int min_waves_per_eu() {
     if (MODE != MODE_FAST) return BASIS == BASIS_25 ? 3 : 4;  // SH25 + counters needs > 128 VGPRs
@@ -955,18 +1064,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     uint32_t st_march_r = 0, st_march_l = 0, st_shade_r = 0, st_shade_l = 0, st_distinct = 0,
              st_fin_r = 0, st_fin_l = 0, st_iter = 0;
 
-#if VR_TIMELINE
-    // (TL_MARK / TL_ADD: defined once below, they use the enclosing function's tl_mark)
-    unsigned long long tl_refill = 0, tl_march = 0, tl_shade_load = 0, tl_shade_math = 0,
-                       tl_shade_acc = 0, tl_total0 = __builtin_readcyclecounter(), tl_mark = 0,
-                       tl_drained = 0;  // when this wave found the ray queue empty
-#define TL_MARK() (tl_mark = __builtin_readcyclecounter())
-#define TL_ADD(v) do { const unsigned long long n_ = __builtin_readcyclecounter(); \
-                       (v) += n_ - tl_mark; tl_mark = n_; } while (0)
-#else
-#define TL_MARK() ((void)0)
-#define TL_ADD(v) ((void)0)
-#endif
+    TL_DECL_FUSED();
     // Colour evaluation of up to 64 queued items, one per lane, whoever owns them;
     // afterwards every owner adds the contributions of its own items, oldest first
     // (= the reference's accumulation order, rt_core.cuh:161).
@@ -1168,9 +1266,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 hi = __builtin_amdgcn_readfirstlane(hi);
                 if (hi == lo) {
                     exhausted = true;
-#if VR_TIMELINE
-                    tl_drained = __builtin_readcyclecounter();
-#endif
+                    TL_QUEUE_DRY();
                 } else {
                     chunk_next = lo;
                     chunk_end = hi;
@@ -1197,13 +1293,11 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     ray.tmax = u2f(ray_word(rs, 10));
                     ray.delta_scale = u2f(ray_word(rs, 11));
                     ray_id = r;
-#if VR_ABLATE != 6
-                    if (HAS_BASIS) {
+                    if (HAS_BASIS && VR_EXP_FUSED_COLOUR) {
 #pragma unroll
                         for (int i = 0; i < NB; ++i)
                             mybasis[i] = u2f(ray_word(rs, kRayWords + i));
                     }
-#endif
                 }
             }
             if (done)
@@ -1285,12 +1379,10 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     weight = ray.light * (1.f - att);
                     if (COUNT && p.render_depth)  // (depth launches take the FULL flavour)
                         ray.out[0] = P::madd(weight, ray.t, ray.out[0]);
-                    else
-#if VR_ABLATE == 6   // timing experiment only: march without any colour work
-                        ray.out[1] += weight;
-#else
+                    else if (VR_EXP_FUSED_COLOUR)
                         push = true;
-#endif
+                    else
+                        ray.out[1] += weight;
                     ray.light *= att;
                     stop = ray.light < p.stop_thresh;
                 }
@@ -1330,19 +1422,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         }
         TL_ADD(tl_march);
     }
-#if VR_TIMELINE
-    if (!COUNT && p.sched_stats && lane == 0) {
-        atomicAdd(&p.sched_stats[0], tl_refill);
-        atomicAdd(&p.sched_stats[1], tl_march);
-        atomicAdd(&p.sched_stats[2], tl_shade_load);
-        atomicAdd(&p.sched_stats[3], tl_shade_math);
-        atomicAdd(&p.sched_stats[4], tl_shade_acc);
-        atomicAdd(&p.sched_stats[5], (unsigned long long)__builtin_readcyclecounter() - tl_total0);
-        atomicAdd(&p.sched_stats[6], 1ull);
-        // the wave's tail: from the moment the queue was empty to its last retired ray
-        atomicAdd(&p.sched_stats[7], (unsigned long long)__builtin_readcyclecounter() - tl_drained);
-    }
-#endif
+    TL_DUMP_FUSED();
     if (COUNT && p.sched_stats && lane == 0) {
         atomicAdd(&p.sched_stats[0], (unsigned long long)st_march_r);
         atomicAdd(&p.sched_stats[1], (unsigned long long)st_march_l);
@@ -1383,13 +1463,17 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
 //   head   (shade -> march)  entries below head are free
 //   cons[64] (shade -> march) items of lane j consumed so far (mod 256): lane j may push while
 //            pushed - cons < kMsOutstanding, which bounds the per-owner table below
-//   ev_*   (march -> shade)  payload of ONE event batch; its ring entry is a marker
-//            (leaf = kMsMarker).  march posts the next batch only after ev_done caught up.
+//   ev_*   (march -> shade)  payload of ONE event batch; the batch takes one ring position
+//            (ev_mask[2]; the entry itself carries nothing) so that it is handled in order with
+//            the items.  march posts the next batch only after ev_done caught up.
 //   flags  (march -> shade)  bit0: march is waiting for the shade wave (shade a partial chunk
 //            instead of waiting for 64 items), bit1: march has finished.
 // Both waves only ever spin on the OTHER wave of their own workgroup (co-resident by
 // construction); march-side waits are bounded and trip the status word instead of hanging.
 // ---------------------------------------------------------------------------
+#ifndef VR_MS_SLEEP
+#define VR_MS_SLEEP 4   // s_sleep argument of the shade wave's idle poll (x 64 cycles)
+#endif
 #ifndef VR_MS_RING
 #define VR_MS_RING 256
 #endif
@@ -1398,7 +1482,6 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
 #endif
 constexpr int kMsRing = VR_MS_RING;   // ring entries (positions are compared mod 2^32)
 constexpr int kMsOutstanding = 8;     // items one lane may have in the ring
-constexpr uint32_t kMsMarker = 0xFFFFFFFFu;
 constexpr uint32_t kMsNoRay = 0x7FFFFFFFu;
 constexpr uint32_t kMsSpinCap = 1u << 22;  // polls before a march-side wait gives up (~0.1 s)
 
@@ -1441,8 +1524,11 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
     __shared__ uint32_t it_leaf[kMsRing];
     __shared__ float it_w[kMsRing];
     __shared__ uint16_t it_own[kMsRing];  // owner lane | (sequence number & 7) << 8
-    __shared__ uint32_t c_tail, c_head, c_flags, c_ev_done;
-    __shared__ uint32_t ev_mask[2];
+    // c_status[0] = tail, c_status[1] = flags | ev_posted << 8: one 8-byte read shows the shade
+    // wave everything the march wave publishes
+    __shared__ __attribute__((aligned(8))) uint32_t c_status[2];
+    __shared__ uint32_t c_head, c_ev_done;
+    __shared__ uint32_t ev_mask[3];       // lanes of the batch (2 words), ring position of the batch
     __shared__ float ev_light[kWave];
     __shared__ uint32_t ev_word[kWave];   // id of the lane's next ray (kMsNoRay: none) | stopped << 31
     __shared__ uint8_t cons[kWave];
@@ -1451,9 +1537,9 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
 
     const int lane = threadIdx.x & (kWave - 1);
     if (threadIdx.x == 0) {
-        c_tail = 0u;
+        c_status[0] = 0u;
+        c_status[1] = 0u;
         c_head = 0u;
-        c_flags = 0u;
         c_ev_done = 0u;
     }
     if (threadIdx.x < kWave) {
@@ -1462,8 +1548,11 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
     }
     __syncthreads();  // the only barrier: from here on the two waves run asynchronously
     const int wpr = kRayWords + p.basis_words;
+    // (the hardware spreads the waves of the workgroups evenly over the four SIMDs of a CU --
+    // measured with HW_ID: each SIMD holds as many march waves as shade waves)
+    const bool is_march = threadIdx.x < (unsigned)kWave;
 
-    if (threadIdx.x < kWave) {
+    if (is_march) {
         // =========================== march wave ===========================
         float cen[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 0.f}, invdir[3] = {1.f, 1.f, 1.f};
         float t = 0.f, tmax = -1.f, delta_scale = 1.f, light = 1.f;
@@ -1476,23 +1565,33 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
         uint32_t chunk_next = 0, chunk_end = 0;
         const uint32_t total = *p.ray_count;
         uint32_t flags_now = 0;
-#if VR_TIMELINE
-        unsigned long long tl_mark = __builtin_readcyclecounter(), tl_m_refill = 0, tl_m_march = 0,
-                           tl_m_stall = 0;
-#endif
+        TL_DECL_MARCH();
         auto give_up = [&]() {  // a wait on the shade wave ran into its cap: report, stop
             if (p.status) atomicOr(p.status, 2u);
             aborted = true;
         };
 
-        while (!aborted) {
+        // One flat loop with a single exit: per iteration an optional refill, then ONE march round
+        // or one poll of the shade wave.  (Nested loops with breaks / continues cost this wave
+        // dozens of scalar instructions per round in exit bookkeeping -- the compiler turns them
+        // into a state machine -- and the scalar unit is shared by the CU's four SIMDs.)
+        bool running = true;
+        uint32_t spins = 0, m_left = 0;  // rounds until the refill conditions are looked at again
+        while (running) {
             TL_ADD(tl_m_march);
             // ---- retire finished rays, hand their lanes new ones ----
+            // (looked at every march_max rounds, and whenever no lane can march)
+            const bool look = m_left == 0u;
+            m_left = __builtin_amdgcn_readfirstlane(look ? (uint32_t)p.march_max : m_left) - 1u;
             const bool done = active && !alive;
-            const unsigned long long m_done = __builtin_amdgcn_ballot_w64(done);
-            const unsigned long long m_free = __builtin_amdgcn_ballot_w64(!active);
-            const unsigned long long m_live = __builtin_amdgcn_ballot_w64(active && alive);
-            const int n_avail = __builtin_popcountll(m_done | m_free);
+            unsigned long long m_done = 0ull, m_free = 0ull, m_live = 1ull;
+            int n_avail = 0;
+            if (look) {
+                m_done = __builtin_amdgcn_ballot_w64(done);
+                m_free = __builtin_amdgcn_ballot_w64(!active);
+                m_live = __builtin_amdgcn_ballot_w64(active && alive);
+                n_avail = __builtin_popcountll(m_done | m_free);
+            }
             if (n_avail > 0 && (m_live == 0ull || (!exhausted && n_avail >= p.refill_min))) {
                 progress_round = rounds;
                 if (!exhausted && chunk_next >= chunk_end) {  // (same queue protocol as render_kernel)
@@ -1561,20 +1660,16 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
                 if (m_ev != 0ull) {
                     // one event batch at a time: the shade wave must have taken the previous one,
                     // and the ring needs a free entry for the marker
-                    uint32_t spins = 0;
-                    while (lds_peek(c_ev_done) != ev_posted ||
-                           tail - lds_peek(c_head) >= (uint32_t)kMsRing) {
+                    uint32_t ev_spins = 0;
+                    while (!aborted && (lds_peek(c_ev_done) != ev_posted ||
+                                        tail - lds_peek(c_head) >= (uint32_t)kMsRing)) {
                         if (!(flags_now & 1u)) {
-                            flags_now |= 1u;
-                            if (lane == 0) lds_post(c_flags, flags_now);
+                            flags_now = __builtin_amdgcn_readfirstlane(flags_now | 1u);
+                            if (lane == 0) lds_post(c_status[1], flags_now | (ev_posted << 8));
                         }
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > kMsSpinCap) {
-                            give_up();
-                            break;
-                        }
+                        if (++ev_spins > kMsSpinCap) give_up();
                     }
-                    if (aborted) break;
                     if (ev) {
                         ev_light[lane] = light;
                         ev_word[lane] = (take ? r : kMsNoRay) | ((done && stopped) ? 0x80000000u : 0u);
@@ -1582,12 +1677,17 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
                     if (lane == 0) {
                         ev_mask[0] = (uint32_t)m_ev;
                         ev_mask[1] = (uint32_t)(m_ev >> 32);
-                        it_leaf[tail & RM] = kMsMarker;
+                        ev_mask[2] = tail;  // the batch's place in the ring (its entry carries nothing)
                     }
                     lds_fence();
-                    tail += 1u;
-                    ev_posted += 1u;
-                    if (lane == 0) lds_post(c_tail, tail);
+                    tail = __builtin_amdgcn_readfirstlane(tail + 1u);
+                    ev_posted = __builtin_amdgcn_readfirstlane(ev_posted + 1u);
+                    if (lane == 0) {
+                        // "a batch is pending" becomes visible BEFORE the tail that covers its ring
+                        // position: the shade wave must never take that position for an item
+                        lds_post(c_status[1], flags_now | (ev_posted << 8));
+                        lds_post(c_status[0], tail);
+                    }
                 }
                 if (vacant) {
                     active = alive = take;
@@ -1596,44 +1696,42 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
                     cur = Cursor();
                 }
             }
-            if (!wave_any(active)) {
-                if (exhausted) break;
-                continue;
-            }
-
-            // ---- march ----
+            // ---- march one round, or wait for the shade wave ----
             TL_ADD(tl_m_refill);
-            uint32_t spins = 0;
-            for (int m = 0; m < p.march_max;) {
-                const bool want = active && alive;
-                if (!wave_any(want)) break;
-                const uint32_t c = *(const __attribute__((address_space(3))) volatile uint8_t*)&cons[lane];
-                const uint32_t head = lds_peek(c_head);
-                const bool go = want && ((pushed - c) & 0xFFu) < (uint32_t)kMsOutstanding;
-                if (!wave_any(go) || tail - head > (uint32_t)(kMsRing - kWave)) {
-                    // every marching ray has kMsOutstanding items in flight, or the ring is full:
-                    // tell the shade wave not to wait for a full chunk, and poll
-                    if (!(flags_now & 1u)) {
-                        flags_now |= 1u;
-                        if (lane == 0) lds_post(c_flags, flags_now);
-                    }
-                    TL_ADD(tl_m_march);
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > kMsSpinCap) {
-                        give_up();
-                        break;
-                    }
-                    TL_ADD(tl_m_stall);
-                    continue;
+            const bool want = active && alive;
+            const uint32_t c = *(const __attribute__((address_space(3))) volatile uint8_t*)&cons[lane];
+            const uint32_t head = __builtin_amdgcn_readfirstlane(lds_peek(c_head));
+            const bool go = want && ((pushed - c) & 0xFFu) < (uint32_t)kMsOutstanding;
+            const bool any_want = wave_any(want);
+            const bool blocked =
+                any_want && (!wave_any(go) || tail - head > (uint32_t)(kMsRing - kWave));
+            TL2_MARK();
+            if (!any_want) {
+                // nothing to march: either the next iteration refills, or this wave is done
+                m_left = 0u;
+                if (exhausted && !wave_any(active)) running = false;
+            } else if (blocked) {
+                // every marching ray has kMsOutstanding items in flight, or the ring is full:
+                // tell the shade wave not to wait for a full chunk, and poll
+                if (!(flags_now & 1u)) {
+                    flags_now = __builtin_amdgcn_readfirstlane(flags_now | 1u);
+                    if (lane == 0) lds_post(c_status[1], flags_now | (ev_posted << 8));
                 }
+                TL_ADD(tl_m_march);
+                __builtin_amdgcn_s_sleep(1);
+                spins = __builtin_amdgcn_readfirstlane(spins + 1u);
+                if (spins > kMsSpinCap) give_up();
+                TL_ADD(tl_m_stall);
+            } else {
+                TL2_COUNT(go);
                 spins = 0;
                 if (flags_now & 1u) {
-                    flags_now &= ~1u;
-                    if (lane == 0) lds_post(c_flags, flags_now);
+                    flags_now = __builtin_amdgcn_readfirstlane(flags_now & ~1u);
+                    if (lane == 0) lds_post(c_status[1], flags_now | (ev_posted << 8));
                 }
-                ++m;
                 // guard against rays that never end, as in render_kernel
-                if (((++rounds) & 1023u) == 0u && rounds - progress_round >= (uint32_t)kMaxIter) {
+                rounds = __builtin_amdgcn_readfirstlane(rounds + 1u);
+                if ((rounds & 1023u) == 0u && rounds - progress_round >= (uint32_t)kMaxIter) {
                     asm volatile("" ::: "memory");
                     if (active && alive) {
                         alive = false;
@@ -1673,6 +1771,7 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
                     }
                 }
                 const unsigned long long m_push = __builtin_amdgcn_ballot_w64(push);
+                TL2_ADD(tl2_query);
                 if (m_push != 0ull) {
                     if (push) {
                         const uint32_t seq =
@@ -1685,22 +1784,17 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
                         it_own[j] = (uint16_t)((uint32_t)lane | ((pushed & 7u) << 8));
                         pushed += 1u;
                     }
-                    tail += (uint32_t)__builtin_popcountll(m_push);
+                    tail = __builtin_amdgcn_readfirstlane(tail + (uint32_t)__builtin_popcountll(m_push));
                     lds_fence();  // the entries are written before the tail moves past them
-                    if (lane == 0) lds_post(c_tail, tail);
+                    if (lane == 0) lds_post(c_status[0], tail);
                 }
+                TL2_ADD(tl2_push);
             }
+            if (aborted) running = false;
         }
-#if VR_TIMELINE
-        if (p.sched_stats && lane == 0) {
-            atomicAdd(&p.sched_stats[0], tl_m_refill);
-            atomicAdd(&p.sched_stats[1], tl_m_march);
-            atomicAdd(&p.sched_stats[2], tl_m_stall);
-            atomicAdd(&p.sched_stats[7], 1ull);
-        }
-#endif
+        TL_DUMP_MARCH();
         lds_fence();
-        if (lane == 0) lds_post(c_flags, 2u);  // finished: everything this wave will ever post is visible
+        if (lane == 0) lds_post(c_status[1], 2u | (ev_posted << 8));  // finished: everything this wave will ever post is visible
     } else {
         // =========================== shade wave ===========================
         float* const res = reinterpret_cast<float*>(stage);  // 3 x 64 floats over the consumed rows
@@ -1712,31 +1806,40 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
         bool s_active = false;
         uint32_t nseq = 0;  // items of this lane consumed so far
         uint32_t head = 0, ev_done = 0;
-#if VR_TIMELINE
-        unsigned long long tl_mark = __builtin_readcyclecounter(), tl_s_idle = 0, tl_s_event = 0,
-                           tl_s_dma = 0, tl_s_math = 0;
-#endif
+        TL_DECL_SHADE();
 
-        for (;;) {
-            const uint32_t flags = lds_peek(c_flags);
-            lds_fence();  // (flags is read before tail: "finished" implies the final tail)
-            const uint32_t tail = lds_peek(c_tail);
+        bool s_running = true;  // (one flat loop with a single exit, like the march wave's)
+        while (s_running) {
+            // ---- poll: ONE LDS read, scalar decisions; nothing else runs while there is nothing to
+            // do (a poll that already peeks at the ring costs ~15 vector instructions, and the
+            // shade waves spend a third of their time here: measured 48 % more VALU instructions
+            // than the fused kernel before this loop was cut down)
+            const unsigned long long st =
+                *(const __attribute__((address_space(3))) volatile unsigned long long*)&c_status[0];
+            const uint32_t tail = __builtin_amdgcn_readfirstlane((uint32_t)st);
+            const uint32_t fl = __builtin_amdgcn_readfirstlane((uint32_t)(st >> 32));
+            const uint32_t flags = fl & 3u;
+            const bool ev_pending = (fl >> 8) != (ev_done & 0xFFFFFFu);
             asm volatile("" ::: "memory");  // ring entries are read after the tail that covers them
             const uint32_t avail = tail - head;
-            // (one structured if / else chain and a single back edge: with `continue`s the
-            // compiler keeps two copies of the lane state and shuffles them at every loop end)
-            if (avail == 0u && (flags & 2u)) break;
+            const bool must_wait =
+                avail == 0u ||
+                (avail < (uint32_t)(VR_MS_MIN_CHUNK < ST::kShade ? VR_MS_MIN_CHUNK : ST::kShade) &&
+                 flags == 0u && !ev_pending);
+            // an event batch holds one ring position (published in ev_mask[2]); items in front of
+            // it are shaded first (a partial chunk), then the batch is handled
             int n = avail < (uint32_t)ST::kShade ? (int)avail : ST::kShade;
+            uint32_t to_marker = 0xFFFFFFFFu;
+            if (ev_pending) to_marker = __builtin_amdgcn_readfirstlane(lds_peek(ev_mask[2])) - head;
+            if (to_marker < (uint32_t)n) n = (int)to_marker;
             const uint32_t jmine = (head + (uint32_t)lane) & RM;
-            const uint32_t myleaf = lane < n ? it_leaf[jmine] : 0u;
-            const unsigned long long m_marker =
-                __builtin_amdgcn_ballot_w64(lane < n && myleaf == kMsMarker);
-            if (m_marker != 0ull && !(m_marker & 1ull)) n = __builtin_ctzll(m_marker);  // items in front of a marker
-            if (avail == 0u || (m_marker == 0ull && n < (VR_MS_MIN_CHUNK < ST::kShade ? VR_MS_MIN_CHUNK : ST::kShade) && !(flags & 3u))) {
+            if (avail == 0u && (flags & 2u)) {
+                s_running = false;  // the march wave has finished and the ring is empty
+            } else if (must_wait) {
                 // nothing to do yet / the march wave is busy producing: wait for a full chunk
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(VR_MS_SLEEP);
                 TL_ADD(tl_s_idle);
-            } else if (m_marker & 1ull) {
+            } else if (to_marker == 0u) {
                 // ---- event batch: finish pixels, take over the lanes' next rays ----
                 asm volatile("" ::: "memory");
                 const unsigned long long mask =
@@ -1782,8 +1885,8 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
                     my_ray = r;
                     out[0] = out[1] = out[2] = 0.f;
                 }
-                head += 1u;
-                ev_done += 1u;
+                head = __builtin_amdgcn_readfirstlane(head + 1u);
+                ev_done = __builtin_amdgcn_readfirstlane(ev_done + 1u);
                 lds_fence();  // the payload has been read before the march wave may overwrite it
                 if (lane == 0) {
                     lds_post(c_head, head);
@@ -1813,12 +1916,9 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
                 else return basis_of(i);
             };
             float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-#if VR_ABLATE == 7   // timing experiment only: the shade wave consumes items without colour work
-            r0 = r1 = r2 = weight;
-            if constexpr (false) {
-#else
-            if constexpr (ST::kEnabled) {
-#endif
+            if constexpr (!VR_EXP_SPLIT_COLOUR) {
+                r0 = r1 = r2 = weight;
+            } else if constexpr (ST::kEnabled) {
 #pragma unroll
                 for (int pass = 0; pass < ST::kPasses; ++pass) {
                     if (pass * ST::kPass < n) {
@@ -1850,7 +1950,7 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
                 const float b0 = HAS_BASIS ? basis_of(0) : 0.f;
                 if (have) {
                     Record<BASIS> rec;
-                    load_record<BASIS>(p, myleaf, rec);
+                    load_record<BASIS>(p, it_leaf[jmine], rec);
                     if (HAS_BASIS) {
                         r0 = weight / (1.f + vr_expf(-(b0 * rec.at(0))));
                         r1 = weight / (1.f + vr_expf(-(b0 * rec.at(1))));
@@ -1901,20 +2001,14 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
                 nseq += taken;
                 cons[ln] = (uint8_t)nseq;
             }
-            head += (uint32_t)n;
+            head = __builtin_amdgcn_readfirstlane(head + (uint32_t)n);
             lds_fence();
             if (lane == 0) lds_post(c_head, head);
             TL_ADD(tl_s_math);
+            TL_SHADE_CHUNK(n);
             }
         }
-#if VR_TIMELINE
-        if (p.sched_stats && lane == 0) {
-            atomicAdd(&p.sched_stats[3], tl_s_idle);
-            atomicAdd(&p.sched_stats[4], tl_s_event);
-            atomicAdd(&p.sched_stats[5], tl_s_dma);
-            atomicAdd(&p.sched_stats[6], tl_s_math);
-        }
-#endif
+        TL_DUMP_SHADE();
     }
 }
 
