@@ -134,3 +134,31 @@ def test_batch_of_poses_both_organisations(torch_cuda, split):
         rgba_o, acc_o, _ = common.oracle_frame(tree, tr, w, h, f)
         assert np.array_equal(got[i], rgba_o), f"pose {i}: RGBA8 differs"
         assert np.array_equal(got_acc[i].view(np.uint32), acc_o.view(np.uint32)), f"pose {i}"
+
+
+def test_tree_with_backward_links(torch_cuda, split):
+    """A valid tree whose node order is scrambled (children at LOWER indices than their parents:
+    relative links may be negative in the file format): the upload's index-order sweep gives up
+    at the first backward link and the general walk takes over; the picture is the oracle's."""
+    from volrend_amd import synth
+    tree = common.small_scene(depth=5, basis_dim=9, seed=391)
+    cap = tree.capacity
+    rng = np.random.default_rng(7)
+    new_of = np.concatenate([[0], 1 + rng.permutation(cap - 1)])        # root stays node 0
+    child = tree.child.reshape(cap, 8).astype(np.int64)
+    tgt = np.where(child != 0, np.arange(cap)[:, None] + child, -1)     # absolute child index
+    new_child = np.zeros_like(child)
+    new_child[new_of] = np.where(tgt >= 0, new_of[np.maximum(tgt, 0)] - new_of[:, None], 0)
+    data = np.empty_like(tree.data.reshape(cap, 8, -1))
+    data[new_of] = tree.data.reshape(cap, 8, -1)
+    assert (new_child < 0).any()
+    scr = synth.SynthTree(new_child.astype(np.int32).reshape(cap, 2, 2, 2),
+                          data.reshape(cap, 2, 2, 2, -1), tree.offset, tree.invradius3,
+                          tree.data_format, tree.extra, tree.depth)
+    tr, w, h, f = common.camera_for(pose_idx=3, size=88)
+    rgba_o, acc_o, _ = common.oracle_frame(tree, tr, w, h, f)           # the ORIGINAL tree
+    rgba_s, acc_s, _ = common.oracle_frame(scr, tr, w, h, f)            # numbering is not geometry
+    assert np.array_equal(rgba_o, rgba_s)
+    rgba_k, acc_k = kernel_frame(torch_cuda, scr, tr, w, h, f)
+    assert np.array_equal(rgba_k, rgba_o)
+    assert np.array_equal(acc_k.view(np.uint32), acc_o.view(np.uint32))

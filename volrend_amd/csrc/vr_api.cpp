@@ -4,6 +4,7 @@
 // pre-computation below must round like the oracle).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -36,6 +37,7 @@ int fail(int code, const char* fmt, ...) {
 struct Tuning {
     int march_max = 16;
     int refill_min = 24;
+    int flush_wait = 0;    // fused kernel: partial shade round once this many ended rays wait for colour (0 = off)
     int waves_per_cu = 0;   // 0: what the kernel flavour fits (vr_kernels.hip waves_per_cu<>)
     int frame_group = 0;   // poses per ray-order group (0 = all poses of the launch, 1 = frame-major)
     int super_block = 1;   // 8x8 blocks per super-block edge in the ray order
@@ -52,6 +54,7 @@ Tuning& default_tuning_locked() {  // call with g_tuning_mutex held
         Tuning x;
         if (const char* e = getenv("VR_MARCH_MAX")) x.march_max = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_REFILL_MIN")) x.refill_min = atoi(e) < 1 ? 1 : atoi(e);
+        if (const char* e = getenv("VR_FLUSH_WAIT")) x.flush_wait = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("VR_WAVES_PER_CU")) x.waves_per_cu = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("VR_FRAME_GROUP")) x.frame_group = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("VR_SUPER_BLOCK")) x.super_block = atoi(e) < 1 ? 1 : atoi(e);
@@ -72,6 +75,7 @@ Tuning default_tuning() {
 bool set_tuning_key(Tuning& tn, const char* key, int value) {
     if (!strcmp(key, "march_max")) tn.march_max = value < 1 ? 1 : value;
     else if (!strcmp(key, "refill_min")) tn.refill_min = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (!strcmp(key, "flush_wait")) tn.flush_wait = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "waves_per_cu")) tn.waves_per_cu = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "frame_group")) tn.frame_group = value < 0 ? 0 : value;
     else if (!strcmp(key, "super_block")) tn.super_block = value < 1 ? 1 : (value > 64 ? 64 : value);
@@ -176,6 +180,46 @@ int validate_topology(const int32_t* child, int64_t cap, int N3, std::vector<uin
         snprintf(why, why_len, "capacity must be positive");
         return -1;
     }
+    // Fast path: files written breadth- or depth-first link every child FORWARD (to a higher
+    // index), and then one sweep in index order sees every parent before its children -- no
+    // queue, sequential reads (a 2 M-node tree: ~20 ms instead of ~50).  The first backward link
+    // abandons the sweep for the general walk below.
+    {
+        level.assign((size_t)cap, 255);
+        level[0] = 0;
+        int depth = 0;
+        bool forward_only = true;
+        for (int64_t n = 0; n < cap && forward_only; ++n) {
+            const uint8_t ln = level[(size_t)n];
+            if (ln == 255) continue;  // not reachable (so far: decided for good if all links go forward)
+            const int32_t* c = child + n * N3;
+            for (int s = 0; s < N3; ++s) {
+                const int64_t skip = c[s];
+                if (skip == 0) continue;
+                const int64_t m = n + skip;
+                if (m <= n) {
+                    forward_only = false;
+                    break;
+                }
+                if (m >= cap) {
+                    snprintf(why, why_len, "node %lld slot %d links outside the tree (%lld)",
+                             (long long)n, s, (long long)m);
+                    return -1;
+                }
+                if (level[(size_t)m] != 255) {
+                    snprintf(why, why_len, "node %lld is linked twice (cycle or DAG)", (long long)m);
+                    return -1;
+                }
+                if (ln + 1 > 60) {
+                    snprintf(why, why_len, "tree deeper than 60 levels");
+                    return -1;
+                }
+                level[(size_t)m] = (uint8_t)(ln + 1);
+                if (ln + 1 > depth) depth = ln + 1;
+            }
+        }
+        if (forward_only) return depth;
+    }
     std::vector<uint8_t> seen((size_t)cap, 0);
     level.assign((size_t)cap, 255);
     level[0] = 0;
@@ -266,86 +310,123 @@ std::vector<int32_t> node_permutation(const int32_t* child, int64_t cap, int N3,
 
 // ---------------------------------------------------------------------------
 // Host -> device copies of the tree arrays at link speed.  hipMemcpy from pageable memory
-// stages through ONE thread's memcpy (~9 GB/s measured: 1.67 GB in 0.19 s); here kCopyWorkers
-// threads each stream their share of the chunks through two pinned slots of their own:
-// memcpy into slot (i & 1) while the DMA of the previous chunk drains slot (i & 1) ^ 1.  No
-// coordination between the workers; the pinned slots are kept in a process-wide free list so
-// that only the first upload allocates them.  Anything small, or any failure to set the
-// pipeline up, falls back to the plain blocking copy.
+// stages through ONE thread's memcpy (~9 GB/s measured: 1.67 GB in 0.19 s); here up to
+// kCopyWorkersMax threads each stream chunks through two pinned slots of their own: memcpy into
+// slot (i & 1) while the DMA of the previous chunk drains slot (i & 1) ^ 1.  All the DMAs go to
+// ONE stream per device (creating a stream costs milliseconds -- an HSA queue -- and the link is
+// the shared resource anyway); that stream and the pinned slots (with their events) live in a
+// process-wide cache, so only the first upload of a process pays for them.  Chunks are claimed
+// dynamically across all segments of a call.  Anything small, or any failure to set the pipeline
+// up, falls back to the plain blocking copy.  VR_UPLOAD_TIMING=1 prints the phases.
 // ---------------------------------------------------------------------------
 constexpr size_t kCopyChunk = 4u << 20;
-constexpr int kCopyWorkersMax = 8;
+constexpr int kCopyWorkersMax = 16;  // (the memcpy side is page-fault bound on mmap'ed files: it scales with threads)
 
-struct PinnedPool {
+struct CopySegment {
+    void* dst;
+    const void* src;
+    size_t bytes;
+};
+struct PinnedSlot {
+    void* mem = nullptr;
+    hipEvent_t done = nullptr;  // the last DMA out of this slot
+    bool used = false;
+};
+struct UploadCache {
     std::mutex mu;
-    std::vector<void*> free_slots;
-    void* take() {
+    std::vector<PinnedSlot> free_slots;
+    hipStream_t stream[16] = {};  // per device, created on first use
+    bool take(PinnedSlot& out) {
         {
             std::lock_guard<std::mutex> g(mu);
             if (!free_slots.empty()) {
-                void* p = free_slots.back();
+                out = free_slots.back();
+                out.used = false;
                 free_slots.pop_back();
-                return p;
+                return true;
             }
         }
-        void* p = nullptr;
-        if (hipHostMalloc(&p, kCopyChunk, hipHostMallocPortable) != hipSuccess) {
+        PinnedSlot sl;
+        if (hipHostMalloc(&sl.mem, kCopyChunk, hipHostMallocPortable) != hipSuccess ||
+            hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
-            return nullptr;
+            if (sl.mem) (void)hipHostFree(sl.mem);
+            return false;
         }
-        return p;
+        out = sl;
+        return true;
     }
-    void give(void* p) {
+    void give(const PinnedSlot& sl) {
         std::lock_guard<std::mutex> g(mu);
-        free_slots.push_back(p);
+        free_slots.push_back(sl);
+    }
+    hipStream_t stream_of(int device) {
+        std::lock_guard<std::mutex> g(mu);
+        if (device < 0 || device >= 16) return nullptr;
+        if (!stream[device] &&
+            hipStreamCreateWithFlags(&stream[device], hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            stream[device] = nullptr;
+        }
+        return stream[device];
     }
 };
-PinnedPool& pinned_pool() {
-    static PinnedPool* pool = new PinnedPool();  // never destroyed: no HIP calls at exit
-    return *pool;
+UploadCache& upload_cache() {
+    static UploadCache* c = new UploadCache();  // never destroyed: no HIP calls at exit
+    return *c;
 }
 
-hipError_t staged_h2d(void* dst, const void* src, size_t bytes, int device) {
-    const size_t n_chunks = (bytes + kCopyChunk - 1) / kCopyChunk;
-    unsigned hw = std::thread::hardware_concurrency();
-    int workers = hw >= 16 ? kCopyWorkersMax : (hw >= 4 ? (int)hw / 2 : 1);
+hipError_t staged_h2d_multi(const CopySegment* seg, int n_seg, int device) {
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t total = 0, n_chunks = 0;
+    std::vector<size_t> first_chunk((size_t)n_seg + 1, 0);
+    for (int i = 0; i < n_seg; ++i) {
+        first_chunk[(size_t)i] = n_chunks;
+        n_chunks += (seg[i].bytes + kCopyChunk - 1) / kCopyChunk;
+        total += seg[i].bytes;
+    }
+    first_chunk[(size_t)n_seg] = n_chunks;
+    auto plain = [&]() {
+        for (int i = 0; i < n_seg; ++i)
+            if (seg[i].bytes) {
+                const hipError_t e = hipMemcpy(seg[i].dst, seg[i].src, seg[i].bytes, hipMemcpyHostToDevice);
+                if (e != hipSuccess) return e;
+            }
+        return hipSuccess;
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    int workers = hw >= 64 ? kCopyWorkersMax : (hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1));
     if ((size_t)workers > n_chunks) workers = (int)n_chunks;
-    if (bytes < (32u << 20) || workers < 2) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    hipStream_t st = (total >= (32u << 20) && workers >= 2) ? upload_cache().stream_of(device) : nullptr;
+    if (!st) return plain();
     std::atomic<int> failed{0};
     std::atomic<size_t> next{0};
     auto work = [&]() {
-        void* slot[2] = {nullptr, nullptr};
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        hipStream_t st = nullptr;
-        bool ok = hipSetDevice(device) == hipSuccess &&
-                  hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; i < 2 && ok; ++i) {
-            slot[i] = pinned_pool().take();
-            ok = slot[i] != nullptr &&
-                 hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
-        }
-        bool used[2] = {false, false};
+        PinnedSlot slot[2];
+        bool ok = hipSetDevice(device) == hipSuccess && upload_cache().take(slot[0]) &&
+                  upload_cache().take(slot[1]);
         // chunks are claimed dynamically (a worker that was scheduled late does not hold the others up)
         for (int k = 0; ok; k ^= 1) {
             const size_t c = next.fetch_add(1);
             if (c >= n_chunks) break;
-            const size_t off = c * kCopyChunk;
-            const size_t len = bytes - off < kCopyChunk ? bytes - off : kCopyChunk;
-            if (used[k]) ok = hipEventSynchronize(ev[k]) == hipSuccess;  // the slot's last DMA is done
+            int si = 0;
+            while (c >= first_chunk[(size_t)si + 1]) ++si;
+            const size_t off = (c - first_chunk[(size_t)si]) * kCopyChunk;
+            const size_t len = seg[si].bytes - off < kCopyChunk ? seg[si].bytes - off : kCopyChunk;
+            if (slot[k].used) ok = hipEventSynchronize(slot[k].done) == hipSuccess;  // its last DMA is done
             if (!ok) break;
-            memcpy(slot[k], static_cast<const char*>(src) + off, len);
-            ok = hipMemcpyAsync(static_cast<char*>(dst) + off, slot[k], len, hipMemcpyHostToDevice,
-                                st) == hipSuccess &&
-                 hipEventRecord(ev[k], st) == hipSuccess;
-            used[k] = true;
+            memcpy(slot[k].mem, static_cast<const char*>(seg[si].src) + off, len);
+            ok = hipMemcpyAsync(static_cast<char*>(seg[si].dst) + off, slot[k].mem, len,
+                                hipMemcpyHostToDevice, st) == hipSuccess &&
+                 hipEventRecord(slot[k].done, st) == hipSuccess;
+            slot[k].used = true;
         }
-        if (st) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
+        for (auto& sl : slot) {
+            if (!sl.mem) continue;
+            if (sl.used && hipEventSynchronize(sl.done) != hipSuccess) ok = false;  // before the slot is reused
+            upload_cache().give(sl);
+        }
         if (!ok) failed.store(1);
-        for (int i = 0; i < 2; ++i) {
-            if (ev[i]) (void)hipEventDestroy(ev[i]);
-            if (slot[i]) pinned_pool().give(slot[i]);
-        }
-        if (st) (void)hipStreamDestroy(st);
     };
     std::vector<std::thread> pool;
     try {
@@ -356,9 +437,20 @@ hipError_t staged_h2d(void* dst, const void* src, size_t bytes, int device) {
     for (auto& t : pool) t.join();
     if (failed.load()) {
         (void)hipGetLastError();
-        return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);  // plain copy of everything
+        (void)hipStreamSynchronize(st);
+        return plain();  // plain copy of everything
+    }
+    if (getenv("VR_UPLOAD_TIMING")) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "[volrend_hip] staged H2D: %.1f MB in %d segments, %d workers, %.1f ms (%.1f GB/s)\n",
+                total / 1e6, n_seg, workers, ms, total / ms / 1e6);
     }
     return hipSuccess;
+}
+
+hipError_t staged_h2d(void* dst, const void* src, size_t bytes, int device) {
+    const CopySegment seg{dst, src, bytes};
+    return staged_h2d_multi(&seg, 1, device);
 }
 
 // same rounding sequence as the oracle's norm3 (strict / fma)
@@ -485,6 +577,8 @@ static hipError_t decode_quant_on_device(const VrTreeDesc* d, const VrQuantDesc*
     void* tmp[4] = {nullptr, nullptr, nullptr, nullptr};
     const void* dev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipError_t e = hipSuccess;
+    CopySegment segs[4];
+    int n_seg = 0;
     for (int i = 0; i < 4 && e == hipSuccess; ++i) {
         if (!sz[i]) continue;
         if (d->memory == 1) {
@@ -492,9 +586,10 @@ static hipError_t decode_quant_on_device(const VrTreeDesc* d, const VrQuantDesc*
             continue;
         }
         e = hipMalloc(&tmp[i], sz[i]);
-        if (e == hipSuccess) e = staged_h2d(tmp[i], src[i], sz[i], device);
+        segs[n_seg++] = CopySegment{tmp[i], src[i], sz[i]};
         dev[i] = tmp[i];
     }
+    if (e == hipSuccess && n_seg) e = staged_h2d_multi(segs, n_seg, device);
     if (e == hipSuccess)
         e = vr::launch_decode_quant((const uint16_t*)dev[0], (const uint16_t*)dev[1],
                                     (const uint16_t*)dev[2], (const uint16_t*)dev[3], d_data,
@@ -564,6 +659,11 @@ static int upload_body(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     const size_t child_sz = n_slots * sizeof(int32_t);
     const size_t data_sz = n_slots * (size_t)d->data_dim * sizeof(uint16_t);
 
+    const bool timing = getenv("VR_UPLOAD_TIMING") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&]() {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    };
     // topology check needs the child words on the host
     std::vector<int32_t> staged;
     const int32_t* host_child = d->child;
@@ -584,18 +684,17 @@ static int upload_body(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     std::thread copier([&] {
         if (e_dev != hipSuccess) return;
         hipError_t e = hipSetDevice(device);
-        if (d->memory != 1) {
-            if (e == hipSuccess) e = hipMalloc((void**)&d_child, child_sz);
-            if (e == hipSuccess) e = staged_h2d(d_child, d->child, child_sz, device);
-        }
+        if (d->memory != 1 && e == hipSuccess) e = hipMalloc((void**)&d_child, child_sz);
+        if ((q || d->memory != 1) && e == hipSuccess) e = hipMalloc((void**)&d_data, data_sz);
         if (q) {  // quantised file: only the codebook arrays cross PCIe, the decode runs on the device
-            if (e == hipSuccess) e = hipMalloc((void**)&d_data, data_sz);
+            if (e == hipSuccess && d->memory != 1) e = staged_h2d(d_child, d->child, child_sz, device);
             if (e == hipSuccess) e = decode_quant_on_device(d, q, n_slots, d_data, device);
-        } else if (d->memory != 1) {
-            if (e == hipSuccess) e = hipMalloc((void**)&d_data, data_sz);
-            if (e == hipSuccess) e = staged_h2d(d_data, d->data, data_sz, device);
+        } else if (d->memory != 1 && e == hipSuccess) {
+            const CopySegment both[2] = {{d_child, d->child, child_sz}, {d_data, d->data, data_sz}};
+            e = staged_h2d_multi(both, 2, device);
         }
         e_copy = e;
+        if (timing) fprintf(stderr, "[volrend_hip] upload: copies done at %.1f ms\n", since());
     });
     struct Joiner {  // every exit below waits for the copies and drops the staging buffers
         std::thread& th;
@@ -654,6 +753,7 @@ static int upload_body(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
         node_permutation(host_child, d->capacity, N3, G0, BL, level, brick_roots);
     // the reference arrays are staged on the device now (unless they already were there);
     // re-layout into nodes/leaves, build the lookup structure, drop the staging copies
+    if (timing) fprintf(stderr, "[volrend_hip] upload: host walks done at %.1f ms\n", since());
     copier.join();
     hipError_t e = e_copy;
     const int32_t* src_child = d->memory != 1 ? d_child : d->child;
@@ -721,6 +821,7 @@ static int upload_body(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
         return fail(e == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP,
                     "tree upload failed: %s", hipGetErrorString(e));
     }
+    if (timing) fprintf(stderr, "[volrend_hip] upload: device-ready at %.1f ms\n", since());
     *out = t;
     return VR_OK;
 }
@@ -1108,6 +1209,7 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
                                       : (t->array_bytes[2] + t->array_bytes[3] > (128ull << 20));
     k.march_max = tn.march_max;
     k.refill_min = tn.refill_min;
+    k.flush_wait = tn.flush_wait;
     k.frame_group = tn.frame_group < 1 || tn.frame_group > n_frames ? n_frames : tn.frame_group;
     k.super_block = tn.super_block;
     // launch slot: per-launch scratch in device memory (ring, see LaunchSlot)

@@ -91,6 +91,7 @@ struct KParams {
     int32_t basis_words;         // basis_fn words per ray in ray_buf (0 for RGBA)
     int32_t refill_min;          // refill once this many lanes are idle
     int32_t march_max;           // march steps per lane between two shade checks
+    int32_t flush_wait;          // fused kernel: shade a partial round once this many ended rays wait for colour (0 = never)
     int32_t instrumented;        // any frame carries counters -> FULL flavour
     int32_t any_accum;           // some frame of the launch asks for its fp32 accumulators
     int32_t records_nt;          // record DMA loads carry the non-temporal hint (large lookup structures)

@@ -1413,6 +1413,17 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 ring_tail += (uint32_t)__builtin_popcountll(m_push);
                 if (ring_tail - ring_head >= (uint32_t)ST::kShade) shade_chunk(ST::kShade);
             }
+            // Lanes whose ray has ended but still has colour items queued can neither march nor
+            // be refilled: once flush_wait of them idle, a partial shade round frees them (the
+            // round costs what a full one costs, so the threshold is a trade: measured below).
+            if (p.flush_wait > 0) {
+                const unsigned long long m_wait =
+                    __builtin_amdgcn_ballot_w64(ray.active && !ray.alive && qsh < 32u);
+                if (__builtin_popcountll(m_wait) >= p.flush_wait && ring_tail != ring_head) {
+                    const uint32_t waiting = ring_tail - ring_head;
+                    shade_chunk(waiting < (uint32_t)ST::kShade ? (int)waiting : ST::kShade);
+                }
+            }
         }
         // nobody can march any more (queues full / rays ended): flush what is queued
         // (at most kShade - 1 + 64 items wait here: two rounds at most)
