@@ -124,10 +124,13 @@ def cpu_baseline(tree, transforms, width, height, focal, budget_s=8.0):
     return out
 
 
-def committed_traffic(config: str, fp: str, profiles_dir: str | None = None, have_hash: str | None = None):
-    """(L2<->fabric bytes per frame, provenance) from the newest profiles/r*_traffic_<config>.json
-    whose recorded kernel-source hash equals the sources this run was built from; (None, reason)
-    when there is no measurement or it is stale."""
+def committed_traffic(config: str, fp: str, profiles_dir: str | None = None, have_hash: str | None = None,
+                      want_fpl: int | None = None):
+    """(L2<->fabric bytes per frame, provenance, frames per launch it was profiled at) from the
+    newest profiles/r*_traffic_<config>[_<frames>].json whose recorded kernel-source hash equals
+    the sources this run was built from -- a measurement taken at THIS run's launch size
+    (``want_fpl``) first, else one at another size (the caller marks it extrapolated);
+    (None, reason, None) when there is no measurement or it is stale."""
     import glob
     if have_hash is None:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -135,14 +138,18 @@ def committed_traffic(config: str, fp: str, profiles_dir: str | None = None, hav
         have_hash = kernel_source_hash()
     profiles_dir = profiles_dir or os.path.join(ROOT, "profiles")
     reason = f"no profiles/r*_traffic_{config}.json"
-    for tpath in sorted(glob.glob(os.path.join(profiles_dir, f"r*_traffic_{config}.json")), reverse=True):
+    found = []
+    for tpath in sorted(glob.glob(os.path.join(profiles_dir, f"r*_traffic_{config}*.json")), reverse=True):
         tj = json.load(open(tpath))
         rel = os.path.join("profiles", os.path.basename(tpath))
-        if tj.get("fp_mode") != fp or "read_bytes_per_frame" not in tj:
+        if tj.get("config") != config or tj.get("fp_mode") != fp or "read_bytes_per_frame" not in tj:
             continue
         if tj.get("kernel_source_sha256") != have_hash:
             reason = f"{rel} is STALE (kernel sources changed since it was measured)"
             continue
+        found.append((tj, rel))
+    found.sort(key=lambda x: 0 if want_fpl is not None and int(x[0]["frames_per_launch"]) == want_fpl else 1)
+    for tj, rel in found[:1]:
         return (tj["read_bytes_per_frame"] + tj.get("write_bytes_per_frame", 0.0),
                 f"{rel}: rocprofv3 --pmc passes at {tj['frames_per_launch']} frames per launch, "
                 f"TCC_EA0_RDREQ_128B*128 + _64B*64 + _32B*32 + WRITE_SIZE, kernel source hash verified",
@@ -509,7 +516,8 @@ def main():
     traffic, traffic_src, traffic_extrapolated = None, None, None
     launch_sizes = [min(B, K - j * B) for j in range(n_launch)]
     if world == 1:
-        per_frame, traffic_src, profiled_fpl = committed_traffic(args.config, args.fp)
+        per_frame, traffic_src, profiled_fpl = committed_traffic(args.config, args.fp,
+                                                                 want_fpl=launch_sizes[0])
         if per_frame is not None:
             traffic = int(per_frame * K / n_launch)
             traffic_extrapolated = any(n != profiled_fpl for n in launch_sizes)

@@ -156,6 +156,15 @@ def test_bench_reports_traffic_only_for_the_sources_it_was_measured_on(tmp_path)
     assert got is None
     got, why, _ = bench.committed_traffic("C9", "strict", str(tmp_path), have_hash="abc")
     assert got is None and "no profiles" in why
+    # a measurement at the run's own launch size wins over one at another size
+    (tmp_path / "r07_traffic_C1_20.json").write_text(json.dumps(dict(rec, frames_per_launch=20,
+                                                                       read_bytes_per_frame=1.1e9)))
+    got, why, fpl = bench.committed_traffic("C1", "strict", str(tmp_path), have_hash="abc", want_fpl=20)
+    assert fpl == 20 and got == 1.105e9 and "r07_traffic_C1_20.json" in why
+    got, why, fpl = bench.committed_traffic("C1", "strict", str(tmp_path), have_hash="abc", want_fpl=64)
+    assert fpl == 64 and got == 1.005e9
+    got, why, fpl = bench.committed_traffic("C1", "strict", str(tmp_path), have_hash="abc", want_fpl=7)
+    assert fpl in (20, 64)  # no profile at 7 frames per launch: the caller marks it extrapolated
     # the real hash covers the kernel sources and the build flags, and is stable
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from measure_traffic import kernel_source_hash

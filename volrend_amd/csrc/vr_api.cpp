@@ -37,6 +37,7 @@ int fail(int code, const char* fmt, ...) {
 struct Tuning {
     int march_max = 16;
     int refill_min = 24;
+    int refill_min_split = 12;  // the split kernel refills more eagerly (its march wave only loads 12 words per ray)
     int flush_wait = 0;    // fused kernel: partial shade round once this many ended rays wait for colour (0 = off)
     int waves_per_cu = 0;   // 0: what the kernel flavour fits (vr_kernels.hip waves_per_cu<>)
     int frame_group = 0;   // poses per ray-order group (0 = all poses of the launch, 1 = frame-major)
@@ -75,6 +76,7 @@ Tuning default_tuning() {
 bool set_tuning_key(Tuning& tn, const char* key, int value) {
     if (!strcmp(key, "march_max")) tn.march_max = value < 1 ? 1 : value;
     else if (!strcmp(key, "refill_min")) tn.refill_min = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (!strcmp(key, "refill_min_split")) tn.refill_min_split = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "flush_wait")) tn.flush_wait = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "waves_per_cu")) tn.waves_per_cu = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "frame_group")) tn.frame_group = value < 0 ? 0 : value;
@@ -1300,6 +1302,9 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     // frames on (profiles/r03_split_vs_fused.jsonl).  SH25's shade state does not fit the split
     // kernel's register budget at all.
     const int split = tn.split >= 0 ? tn.split : (n_frames == 1 && t->desc.basis_dim != 25);
+    const bool fast_n2 = t->desc.N == 2 && t->top_levels > 0 && !instrumented && !k.render_depth &&
+                         t->desc.format != VR_FORMAT_SG && t->desc.format != VR_FORMAT_ASG;
+    if (split && fast_n2) k.refill_min = tn.refill_min_split;  // (only the FAST flavours have a split form)
     HIP_TRY(vr::launch_render(k, f->fp_mode, t->n_cus, tn.waves_per_cu, split, hs));
     return VR_OK;  // (`seal` records the slot's event)
 }
