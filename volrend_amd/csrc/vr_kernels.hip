@@ -159,6 +159,9 @@ constexpr int kWave = 64;
 #ifndef VR_SH16_WAVES
 #define VR_SH16_WAVES 5
 #endif
+#ifndef VR_SH25_WAVES
+#define VR_SH25_WAVES 4
+#endif
 #ifndef VR_SH9_WAVES
 #define VR_SH9_WAVES 6  // (7 fits the LDS but needs 72 VGPRs: scratch)
 #endif
@@ -1003,7 +1006,7 @@ __device__ __forceinline__ void issue_records(const KParams& p, char* stage, con
 template <int BASIS, int MODE>
 constexpr int min_waves_per_eu() {
     if (MODE != MODE_FAST) return BASIS == BASIS_25 ? 3 : 4;  // SH25 + counters needs > 128 VGPRs
-    const int want = BASIS == BASIS_25 ? 4 : BASIS == BASIS_16 ? VR_SH16_WAVES : BASIS == BASIS_9 ? VR_SH9_WAVES : 8;
+    const int want = BASIS == BASIS_25 ? VR_SH25_WAVES : BASIS == BASIS_16 ? VR_SH16_WAVES : BASIS == BASIS_9 ? VR_SH9_WAVES : 8;
     return want < VR_MIN_WAVES_PER_EU ? want : VR_MIN_WAVES_PER_EU;
 }
 // Waves one CU holds of a flavour: the register bound above or the LDS bound (512-byte granules).
@@ -1131,7 +1134,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     if (ST::kPasses == 1 || lane / ST::kPass == pass) {
                         const char* row = stage + (lane % ST::kPass) * ST::kRow;
                         float acc[3];
-                        channel_sums<FMA, BASIS>(row, basis_get, acc);
+                        channel_sums<FMA, BASIS, (VR_SHADE_SCHED_BARRIER != 0) || (BASIS == 25 && VR_SH25_WAVES >= 5)>(row, basis_get, acc);
                         // rt_core.cuh:161: weight / (1 + expf(-tmp)) per channel
                         if constexpr (VR_PACKED_EXP) {
                             const float2v e01 = vr_expf2((float2v){-acc[0], -acc[1]}) + splat2(1.f);
