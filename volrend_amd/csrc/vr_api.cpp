@@ -3,6 +3,7 @@
 // Built with hipcc for gfx950, -ffp-contract=off (the host-side Rodrigues
 // pre-computation below must round like the oracle).
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <chrono>
 #include <cmath>
@@ -314,15 +315,17 @@ std::vector<int32_t> node_permutation(const int32_t* child, int64_t cap, int N3,
 // Host -> device copies of the tree arrays at link speed.  hipMemcpy from pageable memory
 // stages through ONE thread's memcpy (~9 GB/s measured: 1.67 GB in 0.19 s); here up to
 // kCopyWorkersMax threads each stream chunks through two pinned slots of their own: memcpy into
-// slot (i & 1) while the DMA of the previous chunk drains slot (i & 1) ^ 1.  All the DMAs go to
+// slot (i & 1) while the DMA of the previous chunk drains slot (i & 1) ^ 1 (with the source pages
+// mapped ahead of time -- prefault_host_range -- 8 threads keep the link busy: 36-45 GB/s
+// measured; without, the memcpy is page-fault bound at ~20).  All the DMAs go to
 // ONE stream per device (creating a stream costs milliseconds -- an HSA queue -- and the link is
 // the shared resource anyway); that stream and the pinned slots (with their events) live in a
 // process-wide cache, so only the first upload of a process pays for them.  Chunks are claimed
 // dynamically across all segments of a call.  Anything small, or any failure to set the pipeline
 // up, falls back to the plain blocking copy.  VR_UPLOAD_TIMING=1 prints the phases.
 // ---------------------------------------------------------------------------
-constexpr size_t kCopyChunk = 4u << 20;
-constexpr int kCopyWorkersMax = 16;  // (the memcpy side is page-fault bound on mmap'ed files: it scales with threads)
+constexpr size_t kCopyChunk = 2u << 20;  // (pinned memory costs ~0.5 ms per MB to allocate: 8 workers x 2 slots = 32 MB)
+constexpr int kCopyWorkersMax = 4;  // (with the pages mapped ahead, 4 memcpy threads fill the link; every slot is 2 MB of pinned memory to allocate)
 
 struct CopySegment {
     void* dst;
@@ -362,6 +365,17 @@ struct UploadCache {
         std::lock_guard<std::mutex> g(mu);
         free_slots.push_back(sl);
     }
+    // the stream and 2 x kCopyWorkersMax slots up front (first upload of the process)
+    void warm(int device) {
+        (void)stream_of(device);
+        std::vector<PinnedSlot> got;
+        for (int i = 0; i < 2 * kCopyWorkersMax; ++i) {
+            PinnedSlot sl;
+            if (!take(sl)) break;
+            got.push_back(sl);
+        }
+        for (const PinnedSlot& sl : got) give(sl);
+    }
     hipStream_t stream_of(int device) {
         std::lock_guard<std::mutex> g(mu);
         if (device < 0 || device >= 16) return nullptr;
@@ -376,6 +390,38 @@ struct UploadCache {
 UploadCache& upload_cache() {
     static UploadCache* c = new UploadCache();  // never destroyed: no HIP calls at exit
     return *c;
+}
+
+// Maps the pages of a host range into this process ahead of the staged copy (tree files are
+// handed over as views of an mmap'ed npz: every 4 KB page of the 1.6 GB costs a minor fault the
+// first time a copy worker reads it, and the copy is fault-bound).  Runs on a few threads while
+// the HIP runtime starts up; best effort, no effect on results.
+void prefault_host_range(const void* ptr, size_t bytes) {
+    if (!ptr || bytes < (64u << 20)) return;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int n_thr = hw >= 32 ? 8 : (hw >= 8 ? 4 : 1);
+    const uintptr_t page = 4096;
+    const uintptr_t lo = (reinterpret_cast<uintptr_t>(ptr) + page - 1) & ~(page - 1);
+    const uintptr_t hi = (reinterpret_cast<uintptr_t>(ptr) + bytes) & ~(page - 1);
+    if (hi <= lo) return;
+    const uintptr_t per = ((hi - lo) / n_thr + page - 1) & ~(page - 1);
+    auto work = [=](int i) {
+        const uintptr_t a = lo + per * (uintptr_t)i, b = a + per < hi ? a + per : hi;
+        if (a >= b) return;
+        // (one read per page, not madvise(MADV_POPULATE_READ): the bulk call holds the process's
+        // mmap lock for its whole range and the HIP runtime's own mappings -- start-up, every
+        // allocation -- queue up behind it; single faults take the per-VMA lock only)
+        volatile unsigned char sink = 0;
+        for (uintptr_t q = a; q < b; q += page) sink = sink + *reinterpret_cast<const volatile unsigned char*>(q);
+        (void)sink;
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (int i = 1; i < n_thr; ++i) pool.emplace_back(work, i);
+    } catch (...) {
+    }
+    work(0);
+    for (auto& t : pool) t.join();
 }
 
 hipError_t staged_h2d_multi(const CopySegment* seg, int n_seg, int device) {
@@ -397,7 +443,7 @@ hipError_t staged_h2d_multi(const CopySegment* seg, int n_seg, int device) {
         return hipSuccess;
     };
     const unsigned hw = std::thread::hardware_concurrency();
-    int workers = hw >= 64 ? kCopyWorkersMax : (hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1));
+    int workers = hw >= 8 ? kCopyWorkersMax : (hw >= 4 ? 2 : 1);
     if ((size_t)workers > n_chunks) workers = (int)n_chunks;
     hipStream_t st = (total >= (32u << 20) && workers >= 2) ? upload_cache().stream_of(device) : nullptr;
     if (!st) return plain();
@@ -683,11 +729,35 @@ static int upload_body(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     int32_t* d_child = nullptr;
     uint16_t* d_data = nullptr;
     hipError_t e_copy = e_dev;
+    // (the copier only moves the small child array and pays the runtime's start-up before it
+    // looks at `topo`: a malformed file is rejected after ~30 ms of host walk, not after a
+    // multi-GB upload)
+    std::atomic<int> topo{0};  // 0: the check is still running, 1: tree is sound, -1: bad tree
+    // the file's pages are mapped (prefault_host_range) beside the runtime's start-up and the
+    // topology check, ahead of the copy that reads them
+    std::thread prefaulter([&] {
+        if (d->memory != 1 && !q) prefault_host_range(d->data, data_sz);
+    });
+    struct PrefaultJoin {
+        std::thread& th;
+        ~PrefaultJoin() {
+            if (th.joinable()) th.join();
+        }
+    } prefault_join{prefaulter};
     std::thread copier([&] {
         if (e_dev != hipSuccess) return;
         hipError_t e = hipSetDevice(device);
+        // runtime start-up, the allocations and the copy pipeline's pinned slots + stream first:
+        // they need the process's mmap lock exclusively, which a page-mapping pass would hold
         if (d->memory != 1 && e == hipSuccess) e = hipMalloc((void**)&d_child, child_sz);
         if ((q || d->memory != 1) && e == hipSuccess) e = hipMalloc((void**)&d_data, data_sz);
+        if (d->memory != 1 && e == hipSuccess) upload_cache().warm(device);
+        if (timing) fprintf(stderr, "[volrend_hip] upload: runtime + buffers ready at %.1f ms\n", since());
+        while (topo.load(std::memory_order_acquire) == 0) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        if (topo.load(std::memory_order_acquire) < 0) {
+            e_copy = e;
+            return;
+        }
         if (q) {  // quantised file: only the codebook arrays cross PCIe, the decode runs on the device
             if (e == hipSuccess && d->memory != 1) e = staged_h2d(d_child, d->child, child_sz, device);
             if (e == hipSuccess) e = decode_quant_on_device(d, q, n_slots, d_data, device);
@@ -702,8 +772,11 @@ static int upload_body(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
         std::thread& th;
         int32_t*& c;
         uint16_t*& dd;
+        std::atomic<int>& topo;
         bool keep = false;
         ~Joiner() {
+            int pending = 0;
+            topo.compare_exchange_strong(pending, -1);  // (an early exit must not leave the copier waiting)
             if (th.joinable()) th.join();
             if (!keep) {
                 if (c) (void)hipFree(c);
@@ -712,11 +785,19 @@ static int upload_body(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
                 dd = nullptr;
             }
         }
-    } joiner{copier, d_child, d_data};
+    } joiner{copier, d_child, d_data, topo};
 
     char why[256];
     std::vector<uint8_t> level;
-    const int max_depth = validate_topology(host_child, d->capacity, N3, level, why, sizeof(why));
+    int max_depth = -1;
+    try {
+        max_depth = validate_topology(host_child, d->capacity, N3, level, why, sizeof(why));
+    } catch (...) {  // (the copier must be released before the exception travels on)
+        topo.store(-1, std::memory_order_release);
+        throw;
+    }
+    topo.store(max_depth < 0 ? -1 : 1, std::memory_order_release);
+    if (timing) fprintf(stderr, "[volrend_hip] upload: topology checked at %.1f ms\n", since());
     if (max_depth < 0) return fail(VR_ERR_BAD_TREE, "bad tree: %s", why);
     if (e_dev != hipSuccess)
         return fail(VR_ERR_HIP, "hipGetDevice failed: %s", hipGetErrorString(e_dev));

@@ -160,7 +160,7 @@ constexpr int kWave = 64;
 #define VR_SH16_WAVES 5
 #endif
 #ifndef VR_SH25_WAVES
-#define VR_SH25_WAVES 4
+#define VR_SH25_WAVES 4  // (5 = 96 VGPRs + 64 B of scratch with fenced shade math: measured 30 % slower)
 #endif
 #ifndef VR_SH9_WAVES
 #define VR_SH9_WAVES 6  // (7 fits the LDS but needs 72 VGPRs: scratch)
@@ -1465,7 +1465,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
 //       (no wait for its colour) through an event: (light, stopped, id of the lane's next ray).
 //       No basis, no colour state, no shade temporaries: ~45 VGPRs.
 //   wave 1 "shade" : lane j keeps the colour state of march lane j's ray (out[3], basis_fn, the
-//       pixel address).  It consumes the ring in order, 64 items at a time -- record DMA, SH
+//       ray's id).  It consumes the ring in order, 64 items at a time -- record DMA, SH
 //       arithmetic, sigmoid exactly as shade_chunk above -- adds each lane's contributions in
 //       sequence order (= sample order, rt_core.cuh:161), and on an event composites /
 //       quantises / stores the finished pixel and loads the next ray's basis.
@@ -1499,7 +1499,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
 constexpr int kMsRing = VR_MS_RING;   // ring entries (positions are compared mod 2^32)
 constexpr int kMsOutstanding = 8;     // items one lane may have in the ring
 constexpr uint32_t kMsNoRay = 0x7FFFFFFFu;
-constexpr uint32_t kMsSpinCap = 1u << 22;  // polls before a march-side wait gives up (~0.1 s)
+constexpr uint32_t kMsSpinCap = 1u << 22;  // polls before a march-side wait gives up (~0.3 s): status bit 1
 
 __device__ __forceinline__ void lds_fence() {  // LDS accesses of this wave issued so far are done
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
