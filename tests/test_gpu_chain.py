@@ -100,7 +100,10 @@ def test_random_sweep_both_organisations(torch_cuda, split, fp_mode):
     """The seeded random configurations of the CPU pin (formats, odd sizes, cameras inside the
     volume, degenerate thresholds, bbox, basis range, rotation, depth mode, NDC), through both
     kernel organisations and both FP models."""
-    for seed in range(24):
+    # VR_SWEEP_SEEDS=N widens the sweep for a one-off hunt (round 3: 600 seeds, both kernel
+    # organisations, both FP models: clean -- profiles/r03_seed_sweep.txt)
+    import os
+    for seed in range(int(os.environ.get("VR_SWEEP_SEEDS", "24"))):
         tree, tr, w, h, f, ndc, kw, tag = common.random_configuration(seed)
         rgba_o, acc_o, _ = common.oracle_frame(tree, tr, w, h, f, fp_mode, ndc=ndc, **kw)
         rgba_k, acc_k = kernel_frame(torch_cuda, tree, tr, w, h, f, fp_mode, ndc=ndc, **kw)
