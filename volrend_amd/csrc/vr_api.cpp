@@ -139,6 +139,7 @@ struct LaunchSlot {
     hipEvent_t done = nullptr;
     bool used = false;          // `done` has been recorded at least once
     hipStream_t last_stream = nullptr;  // the stream of that launch
+    bool growing = false;       // its ray buffer is being reallocated outside the launch mutex: skip it
     uint32_t* rays = nullptr;   // ray buffer, grown on demand (or up front by vr_reserve)
     size_t ray_bytes = 0;
 };
@@ -1284,8 +1285,8 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.instrumented = instrumented ? 1 : 0;
     k.any_accum = any_accum ? 1 : 0;
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    std::lock_guard<std::mutex> guard(t->launch_mutex);
-    const Tuning& tn = t->tn;
+    std::unique_lock<std::mutex> guard(t->launch_mutex);
+    const Tuning tn = t->tn;  // (a copy: the mutex is dropped once below, while a slot grows)
     // lookup structure (top + bricks) beyond 4x the aggregate L2 (8 x 4 MiB on MI355X): the record
     // stream would keep evicting it -- see the DMA loads in vr_kernels.hip
     k.records_nt = tn.records_nt >= 0 ? tn.records_nt
@@ -1302,7 +1303,7 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
         for (int pass = 0; pass < 2 && slot == kLaunchSlots; ++pass)
             for (unsigned i = 0; i < kLaunchSlots; ++i) {
                 const LaunchSlot& c = t->slots[i];
-                if (want_fit && c.ray_bytes < need) continue;
+                if (c.growing || (want_fit && c.ray_bytes < need)) continue;
                 const bool ok = pass == 0 ? (c.used && c.last_stream == hs)
                                           : (!c.used || hipEventQuery(c.done) == hipSuccess);
                 if (ok) {
@@ -1312,7 +1313,12 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
             }
     }
     (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is an answer, not an error
-    if (slot == kLaunchSlots) slot = t->launch_seq % kLaunchSlots;  // all busy elsewhere: queue up
+    if (slot == kLaunchSlots) {  // all busy elsewhere: queue up behind one (not one that is growing)
+        for (unsigned a = 0; a < kLaunchSlots && slot == kLaunchSlots; ++a)
+            if (!t->slots[(t->launch_seq + a) % kLaunchSlots].growing) slot = (t->launch_seq + a) % kLaunchSlots;
+        if (slot == kLaunchSlots)
+            return fail(VR_ERR_HIP, "all %u launch slots are being resized by other threads", kLaunchSlots);
+    }
     t->launch_seq++;
     LaunchSlot& ls = t->slots[slot];
     k.frames = t->slot_frames + (size_t)slot * vr::kMaxBatch;
@@ -1325,15 +1331,29 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     if (ls.ray_bytes < need) {
         // First use of the slot, or a larger batch than any before: (re)allocate.  This is the
         // one place where an enqueue-only call may block -- on THIS slot's previous launch
-        // only, and hipFree/hipMalloc may synchronise the device; vr_reserve() moves it out of
-        // the render loop.
-        if (ls.rays) {
-            if (ls.used) HIP_TRY(hipEventSynchronize(ls.done));
-            HIP_TRY(hipFree(ls.rays));
-            ls.rays = nullptr;
-            ls.ray_bytes = 0;
+        // only, and hipFree/hipMalloc may synchronise the device; vr_reserve() / vr_reserve_tiles()
+        // move it out of the render loop.
+        // The wait, the free and the allocation run WITHOUT the launch mutex: the slot is marked
+        // `growing` (nobody else picks it) and other threads keep enqueueing on the other slots.
+        ls.growing = true;
+        uint32_t* old_rays = ls.rays;
+        const bool old_used = ls.used;
+        ls.rays = nullptr;
+        ls.ray_bytes = 0;
+        guard.unlock();
+        hipError_t ge = hipSuccess;
+        if (old_rays) {
+            if (old_used) ge = hipEventSynchronize(ls.done);
+            if (ge == hipSuccess) ge = hipFree(old_rays);
         }
-        HIP_TRY(hipMalloc((void**)&ls.rays, need));
+        uint32_t* new_rays = nullptr;
+        if (ge == hipSuccess) ge = hipMalloc((void**)&new_rays, need);
+        guard.lock();
+        ls.growing = false;
+        if (ge != hipSuccess)
+            return fail(ge == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP,
+                        "ray buffer of %zu bytes: %s", need, hipGetErrorString(ge));
+        ls.rays = new_rays;
         ls.ray_bytes = need;
     }
     k.ray_buf_rw = ls.rays;
@@ -1415,7 +1435,7 @@ int vr_reserve_tiles(vr_tree_t t, int width, int height, int n_frames, int tile_
     std::lock_guard<std::mutex> guard(t->launch_mutex);
     for (int i = 0; i < n_slots; ++i) {
         LaunchSlot& ls = t->slots[i];
-        if (ls.ray_bytes >= need) continue;
+        if (ls.ray_bytes >= need || ls.growing) continue;
         if (ls.rays) {
             if (ls.used) HIP_TRY(hipEventSynchronize(ls.done));
             HIP_TRY(hipFree(ls.rays));
