@@ -113,3 +113,55 @@ def test_tree_clone_renders_the_same_frames(torch_cuda):
     with pytest.raises(api._abi.VolrendError):
         r.clone_to(99)
     r.free_device()
+
+
+def test_per_tree_tuning_and_tile_reserve(torch_cuda):
+    """Knobs live in the tree (vr_tree_set_tuning): two trees with opposite kernel organisations
+    render the same bits side by side, a clone inherits its source's knobs, upload-time keys and
+    unknown keys are refused.  vr_reserve_tiles sizes the slots with the launch's own rounding
+    (tile rows that do not divide the height), several slots at once."""
+    torch = torch_cuda
+    from volrend_amd import _abi, api
+    tree = common.small_scene(depth=6, basis_dim=9, seed=515)
+    a = api.N3Tree.from_synth(tree)
+    b = api.N3Tree.from_synth(tree)
+    a.set_tuning(split=1, refill_min=8, march_max=4)
+    b.set_tuning(split=0, refill_min=40, waves_per_cu=12)
+    c = a.clone_to(0)  # inherits split=1, refill_min=8, march_max=4
+    for bad_key in ("top_levels", "brick_levels", "no_such_knob"):
+        with pytest.raises(_abi.VolrendError):
+            a.set_tuning(**{bad_key: 3})
+    w, h = 200, 100  # 100 rows, 24-row tiles: 5 tile rows, the last one ragged
+    f = 260.0
+    trs = [common.camera_for(pose_idx=i, size=64)[0] for i in range(3)]
+    want = [common.oracle_frame(tree, tr, w, h, f, 0)[0] for tr in trs]
+    cam = api.Camera(w, h, f, f)
+    world, tw, th = 2, 200, 24
+    for t in (a, b, c):
+        t.reserve(w, h, len(trs), shard=api.TileShard(tw, th, 0, world, compact=True), n_slots=3)
+        with pytest.raises(_abi.VolrendError):
+            t.reserve(w, h, len(trs), n_slots=9)
+        # whole frames (one launch of 3 poses, then one-frame launches: the split-by-default case)
+        imgs = torch.zeros((len(trs), h, w, 4), dtype=torch.uint8, device="cuda")
+        api.launch_renderer_batch(t, cam, trs, api.RenderOptions(), list(imgs), None, True)
+        single = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        cam.transform = np.asarray(trs[1], np.float32)
+        api.launch_renderer(t, cam, api.RenderOptions(), single, None, None, True)
+        # the tile shard with ragged tile rows, gathered and assembled
+        sh0 = api.TileShard(tw, th, 0, world, compact=True)
+        nbytes = api.compact_bytes(w, h, sh0)
+        gathered = torch.zeros((world, len(trs), nbytes), dtype=torch.uint8, device="cuda")
+        for r in range(world):
+            api.launch_renderer_batch(t, cam, trs, api.RenderOptions(),
+                                      [gathered[r, i] for i in range(len(trs))], None, True,
+                                      shard=api.TileShard(tw, th, r, world, compact=True))
+        outs = torch.zeros((len(trs), h, w, 4), dtype=torch.uint8, device="cuda")
+        api.assemble_tiles_batch(outs, gathered, len(trs), w, h, sh0, torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        assert t.status() == 0
+        assert np.array_equal(single.cpu().numpy(), want[1])
+        for i in range(len(trs)):
+            assert np.array_equal(imgs[i].cpu().numpy(), want[i]), ("frame", i)
+            assert np.array_equal(outs[i].cpu().numpy(), want[i]), ("sharded", i)
+    for t in (a, b, c):
+        t.free_device()
