@@ -31,7 +31,8 @@ constexpr int kWave = 64;
 #define VR_ABLATE 0
 #endif
 #ifndef VR_TIMELINE
-#define VR_TIMELINE 0  // 1: per-phase cycle sums into sched_stats; 2: march-round breakdown (split kernel)
+#define VR_TIMELINE 0  // 1: per-phase cycle sums into sched_stats; 2: + march-round breakdown (split kernel);
+                       // 3: time-resolved tallies of a launch instead (fused kernel)
 #endif
 #if VR_ABLATE == 0
 #define VR_EXP_RECORD_CHUNK(v, j, leaf) ((v)[j])   // 16-byte chunk j of a record (register path)
@@ -39,6 +40,7 @@ constexpr int kWave = 64;
 #define VR_EXP_RECORD_DMA 1                        // record DMAs are issued
 #define VR_EXP_FUSED_COLOUR 1                      // fused kernel: hit samples queue colour work
 #define VR_EXP_SPLIT_COLOUR 1                      // split kernel: the shade wave does its colour work
+#define VR_EXP_STEAL 1                             // waves steal from the ray queues of other XCDs
 #else
 #define VR_EXP_RECORD_CHUNK(v, j, leaf) \
     (VR_ABLATE == 1 ? (v)[0] : VR_ABLATE == 2 ? make_uint4((leaf) + (j), (leaf), (leaf), (leaf)) : (v)[j])
@@ -46,11 +48,15 @@ constexpr int kWave = 64;
 #define VR_EXP_RECORD_DMA (VR_ABLATE != 4)         // 4: no record fetch at all
 #define VR_EXP_FUSED_COLOUR (VR_ABLATE != 6)       // 6: fused kernel marches without colour work
 #define VR_EXP_SPLIT_COLOUR (VR_ABLATE != 7)       // 7: the shade wave only consumes its items
+#define VR_EXP_STEAL (VR_ABLATE != 8)              // 8: every wave stays with the ray queue of its XCD (same pictures)
 #endif
-#if VR_TIMELINE
+#if VR_TIMELINE == 1 || VR_TIMELINE == 2
 #define TL_MARK() (tl_mark = __builtin_readcyclecounter())
 #define TL_ADD(v) do { const unsigned long long n_ = __builtin_readcyclecounter(); \
                        (v) += n_ - tl_mark; tl_mark = n_; } while (0)
+#elif VR_TIMELINE == 3
+#define TL_MARK() (tl3_mark = (uint32_t)__builtin_readcyclecounter())
+#define TL_ADD(v) TL3_TIME(TL3_IDX_##v)
 #else
 #define TL_MARK() ((void)0)
 #define TL_ADD(v) ((void)0)
@@ -66,8 +72,63 @@ constexpr int kWave = 64;
 #define TL2_ADD(v) ((void)0)
 #define TL2_COUNT(go_) ((void)0)
 #endif
+#if VR_TIMELINE == 3
+// time-resolved tallies of the fused kernel: per bucket of 2^15 shader clocks (14.9 us at
+// 2.2 GHz; 64 buckets, counted from the start of the wave -- the waves of a persistent launch
+// all start within ~20 us) the cycles spent in the retire / refill block, marching and shading,
+// the march rounds, the marching lanes, and the waves that ended.  A wave counts in 768 bytes of
+// its LDS (two scalar registers of state: the kernel has none to spare) and adds its table to
+// one of 64 global copies when it ends; read (and cleared) by vr_exp_tl3_read() --
+// tools/tail_profile.py.
+constexpr int kTl3Buckets = 64, kTl3Copies = 64, kTl3Rows = 6;
+__device__ unsigned long long vr_tl3[kTl3Copies][kTl3Rows][kTl3Buckets];
+#define TL3_IDX_tl_refill 0
+#define TL3_IDX_tl_march 1
+#define TL3_IDX_tl_shade_load 2
+#define TL3_IDX_tl_shade_math 2
+#define TL3_IDX_tl_shade_acc 2
+#define TL3_IDX_tl_m_march (-1)  // (the split kernel is not instrumented in this mode)
+#define TL3_IDX_tl_m_refill (-1)
+#define TL3_IDX_tl_m_stall (-1)
+#define TL3_IDX_tl_s_dma (-1)
+#define TL3_IDX_tl_s_event (-1)
+#define TL3_IDX_tl_s_idle (-1)
+#define TL3_IDX_tl_s_math (-1)
+#define TL3_BUCKET(now_) ((((now_) - tl3_clk0) >> 15) & (uint32_t)(kTl3Buckets - 1))
+#define TL3_DECL() __shared__ uint32_t tl3_h[3 * kTl3Buckets];                                      \
+                   for (int k_ = threadIdx.x & 63; k_ < 3 * kTl3Buckets; k_ += 64) tl3_h[k_] = 0;   \
+                   __syncthreads();                                                                 \
+                   const uint32_t tl3_clk0 = (uint32_t)__builtin_readcyclecounter();                \
+                   uint32_t tl3_mark = tl3_clk0
+// words of a bucket: [0] refill | march << 16 (units of 16 clocks), [1] shade | rounds << 16, [2] lanes
+#define TL3_TIME(idx_) do { const uint32_t n_ = (uint32_t)__builtin_readcyclecounter();              \
+        const uint32_t d_ = (n_ - tl3_mark) >> 4; tl3_mark = n_;                                     \
+        if ((idx_) >= 0 && lane == 0)                                                               \
+            atomicAdd(&tl3_h[3 * TL3_BUCKET(n_) + ((idx_) >> 1)], d_ << (16 * ((idx_) & 1))); } while (0)
+#define TL3_ROUND(go_) do { const uint32_t l_ = (uint32_t)__builtin_popcountll(                       \
+                                __builtin_amdgcn_ballot_w64(go_));                                  \
+        if (lane == 0) { const uint32_t b_ = TL3_BUCKET((uint32_t)__builtin_readcyclecounter());    \
+                         atomicAdd(&tl3_h[3 * b_ + 1], 1u << 16); atomicAdd(&tl3_h[3 * b_ + 2], l_); } } while (0)
+#define TL3_SHADE(n_) ((void)0)
+#define TL3_END() do { __syncthreads();                                                             \
+        unsigned long long(*h_)[kTl3Buckets] = vr_tl3[blockIdx.x % kTl3Copies];                     \
+        const uint32_t a_ = tl3_h[3 * lane], b_ = tl3_h[3 * lane + 1], c_ = tl3_h[3 * lane + 2];    \
+        if (a_ | b_ | c_) {                                                                         \
+            atomicAdd(&h_[0][lane], (unsigned long long)(a_ & 0xFFFFu));                            \
+            atomicAdd(&h_[1][lane], (unsigned long long)(a_ >> 16));                                \
+            atomicAdd(&h_[2][lane], (unsigned long long)(b_ & 0xFFFFu));                            \
+            atomicAdd(&h_[3][lane], (unsigned long long)(b_ >> 16));                                \
+            atomicAdd(&h_[4][lane], (unsigned long long)c_);                                        \
+        }                                                                                           \
+        if (lane == 0) atomicAdd(&h_[5][TL3_BUCKET((uint32_t)__builtin_readcyclecounter())], 1ull); } while (0)
+#else
+#define TL3_DECL() ((void)0)
+#define TL3_ROUND(go_) ((void)0)
+#define TL3_SHADE(n_) ((void)0)
+#define TL3_END() ((void)0)
+#endif
 // declarations / dumps of the cycle tallies (sched_stats words: see tools/quick_ab.py, bench.py)
-#if VR_TIMELINE
+#if VR_TIMELINE == 1 || VR_TIMELINE == 2
 #define TL_DECL_FUSED()                                                                          \
     unsigned long long tl_refill = 0, tl_march = 0, tl_shade_load = 0, tl_shade_math = 0,        \
                        tl_shade_acc = 0, tl_total0 = __builtin_readcyclecounter(), tl_mark = 0,  \
@@ -139,8 +200,13 @@ constexpr int kWave = 64;
 #define TL_DECL_FUSED() ((void)0)
 #define TL_QUEUE_DRY() ((void)0)
 #define TL_DUMP_FUSED() ((void)0)
+#if VR_TIMELINE == 3
+#define TL_DECL_MARCH() uint32_t tl3_mark = 0; const uint32_t tl3_clk0 = 0; uint32_t* const tl3_h = nullptr
+#define TL_DECL_SHADE() uint32_t tl3_mark = 0; const uint32_t tl3_clk0 = 0; uint32_t* const tl3_h = nullptr
+#else
 #define TL_DECL_MARCH() ((void)0)
 #define TL_DECL_SHADE() ((void)0)
+#endif
 #define TL_SHADE_CHUNK(n_) ((void)0)
 #define TL_DUMP_MARCH() ((void)0)
 #define TL_DUMP_SHADE() ((void)0)
@@ -857,19 +923,20 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
     using P = Policy<FMA>;
     float* out = ray.out;
     // (COUNT <=> not the FAST flavour: render_depth launches never take FAST, launch_fp)
+    float alpha = out[3];  // (0, or 1 for a depth-mode ray that misses the box: ray generation)
     if (ray.stopped) {  // rt_core.cuh:176-185, applied once every queued colour has landed
         if (COUNT && p.render_depth) out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
         const float scale = 1.f / (1.f - ray.light);
         out[0] *= scale;
         out[1] *= scale;
         out[2] *= scale;
-        out[3] = 1.f;
+        alpha = 1.f;
     } else if (ray.entered) {  // rt_core.cuh:189-194
         if (COUNT && p.render_depth) {
             out[0] = out[1] = out[2] = vmin(out[0] * 0.3f, 1.0f);
-            out[3] = 1.f;
+            alpha = 1.f;
         } else {
-            out[3] = 1.f - ray.light;
+            alpha = 1.f - ray.light;
         }
     }
     if (COUNT && p.frames[frame].counters) {
@@ -894,12 +961,12 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
             const int64_t pix = (int64_t)(xy >> 16) * p.width + (int64_t)(xy & 0xFFFFu);
             // (frame buffers are global memory: say so, a pointer read from a table is "flat" to the
             // compiler and would be accessed with flat_ instructions)
-            ((vr_gfloat4_t*)accum)[pix] = (vr_f4_t){out[0], out[1], out[2], out[3]};
+            ((vr_gfloat4_t*)accum)[pix] = (vr_f4_t){out[0], out[1], out[2], alpha};
         }
     }
     vr_gword_t* const gpx = (vr_gword_t*)px;
     // composite, volrend.cu:152-172
-    const float nalpha = 1.f - out[3];
+    const float nalpha = 1.f - alpha;
     if (p.offscreen) {
         out[0] = P::madd(p.background_brightness, nalpha, out[0]);
         out[1] = P::madd(p.background_brightness, nalpha, out[1]);
@@ -941,6 +1008,64 @@ __device__ __forceinline__ T* ray_slot(T* buf, int words_per_ray, uint32_t r) {
 __device__ __forceinline__ uint32_t ray_word(const uint32_t* slot, int k) { return slot[k * 64]; }
 constexpr int kRing = 128;   // capacity; at most 127 items are ever outstanding
 constexpr int kQueueStride = 16;  // words between queue heads (one 64-byte line each)
+#ifndef VR_STEAL_MIN
+#define VR_STEAL_MIN 8192  // rays a foreign queue must still hold to be worth a steal
+#endif
+constexpr int kHintBase = 8 * kQueueStride + 16;  // words from queue head 0 to the first hint word
+constexpr int kHintCopies = 64;                   // hint words, 16 words apart (one line each)
+
+// A wave's next private range [lo, hi) of ray ids, or lo == hi when there is nothing left for it.
+// The ray buffer is cut into n_queues (1 or 8) contiguous ranges (= screen regions of the batch,
+// see locate()), each with its own head word; a wave serves the range of its XCD first
+// (workgroup b runs on XCD b % 8 -- used for L2 affinity only, never for correctness) and steals
+// from the others when that range has run dry.  Chunk sizes shrink as a queue drains (guided
+// self-scheduling) so the tail stays balanced.
+//   * One lane walks the queues: one load per queue, and ONE returning atomic on the queue that is
+//     picked.  A single word sustains ~90 accesses per microsecond chip-wide -- loads included:
+//     requests to one line are served one after the other.
+//   * When the queues run dry -- all at about the same time -- every wave learns it by walking all
+//     of them: 5000 waves x 8 loads on 8 lines held the chip at a third of its march rate for
+//     50 us of a one-frame launch (profiles/r03_tail_profile.jsonl).  So waves share what they
+//     find: kHintCopies words (a wave uses copy (b / 8) % 64, i.e. ~80 waves of all XCDs per
+//     word) hold a bit per queue "seen dry"; a wave whose own queue is dry reads its hint word
+//     and only visits the queues nobody has reported yet.  Hints are only ever set for a queue
+//     whose head has passed its end, and heads only grow: a stale hint costs a visit, never a ray.
+__device__ __forceinline__ void grab_chunk(const KParams& p, uint32_t total, int lane, uint32_t& lo,
+                                           uint32_t& hi) {
+    lo = hi = 0;
+    if (lane == 0) {
+        const uint32_t nq = (uint32_t)p.n_queues;
+        const uint32_t mine = blockIdx.x % nq;
+        const uint32_t waves_per_q = (gridDim.x + nq - 1) / nq;
+        uint32_t* const hint = p.queue_head + kHintBase + ((blockIdx.x >> 3) % kHintCopies) * kQueueStride;
+        uint32_t dry = 0, found_dry = 0;
+        for (uint32_t a = 0; a < (VR_EXP_STEAL ? nq : 1u); ++a) {
+            const uint32_t x = (mine + a) % nq;
+            if (a == 1u)  // the own queue is dry: what do the others say?
+                dry = __hip_atomic_load(hint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((dry >> x) & 1u) continue;
+            const uint32_t qlo = (uint32_t)((uint64_t)total * x / nq);
+            const uint32_t qhi = (uint32_t)((uint64_t)total * (x + 1) / nq);
+            const uint32_t len = qhi - qlo;
+            uint32_t* head = p.queue_head + x * kQueueStride;
+            const uint32_t seen = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a != 0u && seen < len && len - seen < (uint32_t)VR_STEAL_MIN) continue;  // not worth a steal
+            if (seen < len) {
+                uint32_t size = (len - seen) / (2u * waves_per_q);
+                size = size < 64u ? 64u : (size > (uint32_t)p.chunk_max ? (uint32_t)p.chunk_max : size);
+                size &= ~63u;
+                const uint32_t base = atomicAdd(head, size);
+                if (base < len) {
+                    lo = qlo + base;
+                    hi = base + size < len ? qlo + base + size : qhi;
+                    break;
+                }
+            }
+            found_dry |= 1u << x;
+        }
+        if (nq > 1u && (found_dry & ~dry) != 0u) atomicOr(hint, found_dry);
+    }
+}
 
 // Record fetch of a shade round: a record of V 16-byte chunks is fetched by V adjacent lanes
 // (one or two cache lines per group instead of one line per lane and chunk) with LDS-DMA loads:
@@ -1068,11 +1193,13 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
              st_fin_r = 0, st_fin_l = 0, st_iter = 0;
 
     TL_DECL_FUSED();
+    TL3_DECL();
     // Colour evaluation of up to 64 queued items, one per lane, whoever owns them;
     // afterwards every owner adds the contributions of its own items, oldest first
     // (= the reference's accumulation order, rt_core.cuh:161).
     auto shade_chunk = [&](int n) {
         TL_ADD(tl_march);
+        TL3_SHADE(n);
         __syncthreads();  // item pushes are visible
         if (COUNT) {
             st_shade_r++;
@@ -1235,36 +1362,8 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
             // microsecond chip-wide) when the chunk is used up; chunk sizes shrink as the
             // queue drains (guided self-scheduling) so the tail stays balanced.
             if (!exhausted && chunk_next >= chunk_end) {
-                // The ray buffer is cut into n_queues contiguous ranges (= screen regions of
-                // the batch, see locate()), each with its own head word; a wave serves the
-                // range of its XCD first (workgroup b runs on XCD b % 8 -- used for L2
-                // affinity only, never for correctness) and steals from the others when that
-                // range has run dry.
-                uint32_t lo = 0, hi = 0;
-                if (lane == 0) {
-                    const uint32_t nq = (uint32_t)p.n_queues;
-                    const uint32_t mine = blockIdx.x % nq;
-                    const uint32_t waves_per_q = (gridDim.x + nq - 1) / nq;
-                    for (uint32_t a = 0; a < nq; ++a) {
-                        const uint32_t x = (mine + a) % nq;
-                        const uint32_t qlo = (uint32_t)((uint64_t)total * x / nq);
-                        const uint32_t qhi = (uint32_t)((uint64_t)total * (x + 1) / nq);
-                        const uint32_t len = qhi - qlo;
-                        uint32_t* head = p.queue_head + x * kQueueStride;
-                        const uint32_t seen =
-                            __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (seen >= len) continue;
-                        uint32_t size = (len - seen) / (2u * waves_per_q);
-                        size = size < 64u ? 64u : (size > (uint32_t)p.chunk_max ? (uint32_t)p.chunk_max : size);
-                        size &= ~63u;
-                        const uint32_t base = atomicAdd(head, size);
-                        if (base < len) {
-                            lo = qlo + base;
-                            hi = base + size < len ? qlo + base + size : qhi;
-                            break;
-                        }
-                    }
-                }
+                uint32_t lo, hi;
+                grab_chunk(p, total, lane, lo, hi);
                 lo = __builtin_amdgcn_readfirstlane(lo);
                 hi = __builtin_amdgcn_readfirstlane(hi);
                 if (hi == lo) {
@@ -1345,6 +1444,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 st_march_r++;
                 st_march_l += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(go));
             }
+            TL3_ROUND(go);
             bool push = false;
             uint32_t leaf = 0;
             float weight = 0.f;
@@ -1439,6 +1539,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         TL_ADD(tl_march);
     }
     TL_DUMP_FUSED();
+    TL3_END();
     if (COUNT && p.sched_stats && lane == 0) {
         atomicAdd(&p.sched_stats[0], (unsigned long long)st_march_r);
         atomicAdd(&p.sched_stats[1], (unsigned long long)st_march_l);
@@ -1611,32 +1712,8 @@ __global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_
             if (n_avail > 0 && (m_live == 0ull || (!exhausted && n_avail >= p.refill_min))) {
                 progress_round = rounds;
                 if (!exhausted && chunk_next >= chunk_end) {  // (same queue protocol as render_kernel)
-                    uint32_t lo = 0, hi = 0;
-                    if (lane == 0) {
-                        const uint32_t nq = (uint32_t)p.n_queues;
-                        const uint32_t mine = blockIdx.x % nq;
-                        const uint32_t waves_per_q = (gridDim.x + nq - 1) / nq;
-                        for (uint32_t a = 0; a < nq; ++a) {
-                            const uint32_t x = (mine + a) % nq;
-                            const uint32_t qlo = (uint32_t)((uint64_t)total * x / nq);
-                            const uint32_t qhi = (uint32_t)((uint64_t)total * (x + 1) / nq);
-                            const uint32_t len = qhi - qlo;
-                            uint32_t* head = p.queue_head + x * kQueueStride;
-                            const uint32_t seen =
-                                __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (seen >= len) continue;
-                            uint32_t size = (len - seen) / (2u * waves_per_q);
-                            size = size < 64u ? 64u
-                                              : (size > (uint32_t)p.chunk_max ? (uint32_t)p.chunk_max : size);
-                            size &= ~63u;
-                            const uint32_t base = atomicAdd(head, size);
-                            if (base < len) {
-                                lo = qlo + base;
-                                hi = base + size < len ? qlo + base + size : qhi;
-                                break;
-                            }
-                        }
-                    }
+                    uint32_t lo, hi;
+                    grab_chunk(p, total, lane, lo, hi);
                     lo = __builtin_amdgcn_readfirstlane(lo);
                     hi = __builtin_amdgcn_readfirstlane(hi);
                     if (hi == lo) {
@@ -2126,6 +2203,7 @@ __global__ void prepare_launch_kernel(FrameTable tbl, FrameDesc* frames, uint32_
     if (i < tbl.n) frames[tbl.first + i] = tbl.f[i];
     if (tbl.first == 0) {
         if (i < 8) queue_head[i * kQueueStride] = 0u;
+        if (i < kHintCopies) queue_head[kHintBase + i * kQueueStride] = 0u;
         if (i == 0) *ray_count = 0u;
     }
 }
@@ -2560,3 +2638,23 @@ hipError_t launch_decode_quant(const uint16_t* colors, const uint16_t* map, cons
 }
 
 }  // namespace vr
+
+#if VR_TIMELINE == 3
+// experiment builds only (see the hooks at the top of this file): out = [kTl3Rows][kTl3Buckets] sums
+extern "C" int vr_exp_tl3_read(unsigned long long* out, int reset) {
+    using namespace vr;
+    static unsigned long long host[kTl3Copies][kTl3Rows][kTl3Buckets];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(vr_tl3), sizeof(host)) != hipSuccess) return -1;
+    for (int r = 0; r < kTl3Rows; ++r)
+        for (int b = 0; b < kTl3Buckets; ++b) {
+            unsigned long long v = 0;
+            for (int c = 0; c < kTl3Copies; ++c) v += host[c][r][b];
+            out[r * kTl3Buckets + b] = v;
+        }
+    if (reset) {
+        for (auto& c : host) for (auto& r : c) for (auto& v : r) v = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(vr_tl3), host, sizeof(host)) != hipSuccess) return -1;
+    }
+    return kTl3Buckets;
+}
+#endif
