@@ -1,5 +1,5 @@
 # Round-end measurement set (run through gpurun from the repo root):  bash tools/job_final.sh <round tag>
-# ~35 GPU-minutes.  Everything lands in gpurun_out/<tag>/; the traffic JSONs are also copied to
+# ~8 GPU-minutes.  Everything lands in gpurun_out/<tag>/; the traffic JSONs are also copied to
 # profiles/ at once so that the bench lines taken afterwards can report them (source hash verified).
 set -u
 R=${1:-r03}
@@ -33,7 +33,19 @@ bash tools/lone_launch.sh $R > /dev/null 2>&1; cp gpurun_out/lone_$R.jsonl $O/${
 VR_TIMELINE=1 VOLREND_HIP_LIB=$PWD/volrend_amd/libvolrend_hip_tl.so timeout 300 python bench.py --no-cpu-baseline --no-parity 2>&1 >/dev/null | grep timeline > $O/${R}_timeline.txt
 VR_TIMELINE=1 VOLREND_HIP_LIB=$PWD/volrend_amd/libvolrend_hip_tl.so timeout 600 python bench.py --config C3 --no-cpu-baseline --no-parity 2>&1 >/dev/null | grep timeline | sed -e "s/^/C3: /" >> $O/${R}_timeline.txt
 VR_TIMELINE=1 timeout 300 python tools/quick_ab.py --config C1 --variants tl --tunes "split=1" --frames 1,64 --reps 3 --out $O/${R}_timeline_split.jsonl > /dev/null 2>&1
+VR_TIMELINE=1 timeout 300 python tools/tail_profile.py --frames 1 --tunes "split=0" --out $O/${R}_tail_profile_final.jsonl > /dev/null 2>&1
 bash tools/kernel_resources.sh > $O/${R}_kernel_resources.txt 2>&1
+# --- bench-shaped launches against the CPU oracle, frame by frame, and the wide random sweep
+rm -f $O/${R}_batch_parity.jsonl
+timeout 600 python tools/check_batch_parity.py C1 64 64 0 >> $O/${R}_batch_parity.jsonl 2>/dev/null
+timeout 600 python tools/check_batch_parity.py C1 64 64 1 >> $O/${R}_batch_parity.jsonl 2>/dev/null
+timeout 600 python tools/check_batch_parity.py C1 1 17 -1 >> $O/${R}_batch_parity.jsonl 2>/dev/null
+timeout 900 python tools/check_batch_parity.py C3 16 30 0 >> $O/${R}_batch_parity.jsonl 2>/dev/null
+timeout 900 python tools/check_batch_parity.py C3 16 30 1 >> $O/${R}_batch_parity.jsonl 2>/dev/null
+timeout 900 python tools/check_batch_parity.py C2 8 10 -1 >> $O/${R}_batch_parity.jsonl 2>/dev/null
+VR_SWEEP_SEEDS=600 timeout 1500 python -m pytest tests/test_gpu_chain.py -q -x --timeout 1400 -k "random_sweep" > $O/seed_sweep_chain.log 2>&1
+VR_SWEEP_SEEDS=600 timeout 1500 python -m pytest tests/test_gpu_parity.py -q -x --timeout 1400 -k "sweep or random" > $O/seed_sweep_parity.log 2>&1
+( echo "VR_SWEEP_SEEDS=600 pytest tests/test_gpu_chain.py -k random_sweep:"; tail -1 $O/seed_sweep_chain.log; echo "VR_SWEEP_SEEDS=600 pytest tests/test_gpu_parity.py -k 'sweep or random':"; tail -1 $O/seed_sweep_parity.log ) > $O/${R}_seed_sweep.txt
 timeout 900 python tools/cli_bench.py > $O/${R}_cli_bench.json 2> $O/cli_bench.log
 timeout 900 python tools/upload_bench.py > $O/${R}_upload_bench.json 2> $O/upload_bench.log
 python - <<PY

@@ -125,8 +125,7 @@ class DeviceGuard {
 }  // namespace
 
 constexpr unsigned kLaunchSlots = 8;
-constexpr unsigned kSlotWords = 160 + 64 * 16;  // [0] ray count, [16 + 16*x] queue head x (x < 8),
-                                               // [160 + 16*c] dry-queue hint word c (c < 64)
+constexpr unsigned kSlotWords = 160;  // [0] ray count, [16 + 16*x] queue head x (x < 8)
 
 // Per-launch scratch that a kernel reads while it runs: frame table, queue heads, ray count,
 // ray buffer, probe coefficients.  `done` is recorded on the launch's stream behind its last

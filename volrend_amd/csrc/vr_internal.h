@@ -81,8 +81,7 @@ struct KParams {
     int64_t n_wave_blocks;       // per frame: n_local_tiles * wblocks_per_tile
     uint32_t total_rays;         // n_frames * n_wave_blocks * 64
     // ---- persistent scheduling ----
-    uint32_t* queue_head;        // 8 head words, 16 words apart, and 64 hint words behind them (see
-                                 // grab_chunk), all reset by prepare_launch_kernel
+    uint32_t* queue_head;        // 8 head words, 16 words apart, reset by prepare_launch_kernel
     int32_t n_queues;            // 1 or 8 (one ray-id range per XCD)
     int32_t chunk_max;           // largest ray-id chunk a wave takes at once (multiple of 64)
     const uint32_t* ray_buf;     // compacted rays (written by raygen_kernel), SoA, stride total_rays

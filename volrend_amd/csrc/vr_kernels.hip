@@ -1009,10 +1009,8 @@ __device__ __forceinline__ uint32_t ray_word(const uint32_t* slot, int k) { retu
 constexpr int kRing = 128;   // capacity; at most 127 items are ever outstanding
 constexpr int kQueueStride = 16;  // words between queue heads (one 64-byte line each)
 #ifndef VR_STEAL_MIN
-#define VR_STEAL_MIN 8192  // rays a foreign queue must still hold to be worth a steal
+#define VR_STEAL_MIN 8192  // rays a foreign queue must still hold to be worth a steal (or an eighth of its length)
 #endif
-constexpr int kHintBase = 8 * kQueueStride + 16;  // words from queue head 0 to the first hint word
-constexpr int kHintCopies = 64;                   // hint words, 16 words apart (one line each)
 
 // A wave's next private range [lo, hi) of ray ids, or lo == hi when there is nothing left for it.
 // The ray buffer is cut into n_queues (1 or 8) contiguous ranges (= screen regions of the batch,
@@ -1021,49 +1019,46 @@ constexpr int kHintCopies = 64;                   // hint words, 16 words apart 
 // from the others when that range has run dry.  Chunk sizes shrink as a queue drains (guided
 // self-scheduling) so the tail stays balanced.
 //   * One lane walks the queues: one load per queue, and ONE returning atomic on the queue that is
-//     picked.  A single word sustains ~90 accesses per microsecond chip-wide -- loads included:
-//     requests to one line are served one after the other.
-//   * When the queues run dry -- all at about the same time -- every wave learns it by walking all
-//     of them: 5000 waves x 8 loads on 8 lines held the chip at a third of its march rate for
-//     50 us of a one-frame launch (profiles/r03_tail_profile.jsonl).  So waves share what they
-//     find: kHintCopies words (a wave uses copy (b / 8) % 64, i.e. ~80 waves of all XCDs per
-//     word) hold a bit per queue "seen dry"; a wave whose own queue is dry reads its hint word
-//     and only visits the queues nobody has reported yet.  Hints are only ever set for a queue
-//     whose head has passed its end, and heads only grow: a stale hint costs a visit, never a ray.
+//     picked.  A single word sustains ~90 accesses per microsecond chip-wide (one queue for the
+//     whole chip: a one-frame launch takes 40 % longer, profiles/r03_steal_threshold.jsonl).
+//   * Waves steal from a queue only while it holds a good part of its rays (an eighth, at most
+//     VR_STEAL_MIN); the rest is left to the queue's own waves.  Stealing down to the last chunk
+//     -- round 2 -- had every wave of the chip visit every queue when they ran dry, all at
+//     about the same time, and scattered the last blocks of every screen region over all
+//     XCDs: a one-frame launch marched at a third of its rate for 50 us
+//     (profiles/r03_tail_profile.jsonl; without any stealing a 20-frame launch is 5 % slower).
+//     A wave only reports "nothing left" after its OWN queue has run dry, so every queue is
+//     drained by the waves it belongs to -- which a grid of fewer waves than queues does not
+//     have for every queue: such a grid steals to the end.
 __device__ __forceinline__ void grab_chunk(const KParams& p, uint32_t total, int lane, uint32_t& lo,
                                            uint32_t& hi) {
     lo = hi = 0;
     if (lane == 0) {
-        const uint32_t nq = (uint32_t)p.n_queues;
-        const uint32_t mine = blockIdx.x % nq;
-        const uint32_t waves_per_q = (gridDim.x + nq - 1) / nq;
-        uint32_t* const hint = p.queue_head + kHintBase + ((blockIdx.x >> 3) % kHintCopies) * kQueueStride;
-        uint32_t dry = 0, found_dry = 0;
+        const uint32_t nq = (uint32_t)p.n_queues;  // 1 or 8
+        const uint32_t sh = nq == 8u ? 3u : 0u;    // queue x = ray ids [total * x / nq, total * (x + 1) / nq)
+        const uint32_t mine = blockIdx.x & (nq - 1u);
+        const uint32_t waves_per_q = (gridDim.x + nq - 1u) >> sh;
         for (uint32_t a = 0; a < (VR_EXP_STEAL ? nq : 1u); ++a) {
-            const uint32_t x = (mine + a) % nq;
-            if (a == 1u)  // the own queue is dry: what do the others say?
-                dry = __hip_atomic_load(hint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((dry >> x) & 1u) continue;
-            const uint32_t qlo = (uint32_t)((uint64_t)total * x / nq);
-            const uint32_t qhi = (uint32_t)((uint64_t)total * (x + 1) / nq);
+            const uint32_t x = (mine + a) & (nq - 1u);
+            const uint32_t qlo = (uint32_t)((uint64_t)total * x >> sh);
+            const uint32_t qhi = (uint32_t)((uint64_t)total * (x + 1u) >> sh);
             const uint32_t len = qhi - qlo;
             uint32_t* head = p.queue_head + x * kQueueStride;
             const uint32_t seen = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a != 0u && seen < len && len - seen < (uint32_t)VR_STEAL_MIN) continue;  // not worth a steal
-            if (seen < len) {
-                uint32_t size = (len - seen) / (2u * waves_per_q);
-                size = size < 64u ? 64u : (size > (uint32_t)p.chunk_max ? (uint32_t)p.chunk_max : size);
-                size &= ~63u;
-                const uint32_t base = atomicAdd(head, size);
-                if (base < len) {
-                    lo = qlo + base;
-                    hi = base + size < len ? qlo + base + size : qhi;
-                    break;
-                }
+            if (seen >= len) continue;
+            if (a != 0u && gridDim.x >= nq &&
+                len - seen < ((len >> 3) < (uint32_t)VR_STEAL_MIN ? (len >> 3) : (uint32_t)VR_STEAL_MIN))
+                continue;  // not worth a steal
+            uint32_t size = (len - seen) / (2u * waves_per_q);
+            size = size < 64u ? 64u : (size > (uint32_t)p.chunk_max ? (uint32_t)p.chunk_max : size);
+            size &= ~63u;
+            const uint32_t base = atomicAdd(head, size);
+            if (base < len) {
+                lo = qlo + base;
+                hi = base + size < len ? qlo + base + size : qhi;
+                break;
             }
-            found_dry |= 1u << x;
         }
-        if (nq > 1u && (found_dry & ~dry) != 0u) atomicOr(hint, found_dry);
     }
 }
 
@@ -2203,7 +2198,6 @@ __global__ void prepare_launch_kernel(FrameTable tbl, FrameDesc* frames, uint32_
     if (i < tbl.n) frames[tbl.first + i] = tbl.f[i];
     if (tbl.first == 0) {
         if (i < 8) queue_head[i * kQueueStride] = 0u;
-        if (i < kHintCopies) queue_head[kHintBase + i * kQueueStride] = 0u;
         if (i == 0) *ray_count = 0u;
     }
 }
