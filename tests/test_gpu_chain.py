@@ -165,3 +165,34 @@ def test_tree_with_backward_links(torch_cuda, split):
     rgba_k, acc_k = kernel_frame(torch_cuda, scr, tr, w, h, f)
     assert np.array_equal(rgba_k, rgba_o)
     assert np.array_equal(acc_k.view(np.uint32), acc_o.view(np.uint32))
+
+
+@pytest.mark.parametrize("xcd_queues", [1, 0], ids=["8 queues", "1 queue"])
+def test_every_ray_queue_is_drained(torch_cuda, split, xcd_queues):
+    """The ray buffer is cut into 8 queues, one per XCD; a wave steals from a foreign queue only
+    while that queue holds a good part of its rays and leaves the rest to the queue's own waves
+    (vr_kernels.hip, grab_chunk).  A launch of fewer waves than queues has queues WITHOUT waves of
+    their own and must steal to the end; launches of a few, of about eight and of many waves, and
+    the one-queue layout, all have to deliver every pixel the oracle delivers."""
+    from volrend_amd import api
+    tree = common.small_scene(depth=6, basis_dim=9, seed=407)
+    t = api.N3Tree.from_synth(tree)
+    t.set_tuning(xcd_queues=xcd_queues)
+    torch = torch_cuda
+    try:
+        for w, h in ((8, 8), (17, 9), (24, 24), (40, 24), (64, 56), (128, 120), (264, 200)):
+            f = w * 1111.111 / 800.0 * 1.3
+            tr, _, _, _ = common.camera_for(pose_idx=5, size=w)
+            cam = api.Camera(w, h, f, f)
+            cam.transform = np.asarray(tr, dtype=np.float32)
+            img = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+            acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+            api.launch_renderer(t, cam, api.RenderOptions(), img, None, torch.cuda.current_stream(),
+                                True, accum=acc)
+            torch.cuda.synchronize()
+            assert t.status() == 0
+            rgba_o, acc_o, cnt = common.oracle_frame(tree, tr, w, h, f)
+            assert np.array_equal(img.cpu().numpy(), rgba_o), f"{w}x{h}: RGBA8 differs"
+            assert np.array_equal(acc.cpu().numpy().view(np.uint32), acc_o.view(np.uint32)), f"{w}x{h}"
+    finally:
+        t.free_device()
