@@ -197,3 +197,23 @@ def test_measure_traffic_parses_rocprofv3_csvs(tmp_path):
     assert sorted(dur) == [2000.0, 4000.0]
     # the group table never offers the counters that abort rocprofv3 on this pool
     assert not any(c.startswith(("TA_", "TD_")) for g in mt.GROUPS.values() for c in g.split())
+
+
+def test_drain_simulation_conserves_rays():
+    """tools/drain_sim.py (the model behind DESIGN.md section 7's bound on re-grouping the rays of
+    the drain phase): every policy marches every sample of every ray, a free exchange is never
+    slower than no exchange, and phases hand over exactly the rays they did not finish."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import drain_sim as ds
+    rng = np.random.default_rng(3)
+    rays = np.minimum(rng.geometric(1.0 / 30.0, size=64 * 300), 400).astype(np.int32)
+    base, phases = ds.simulate(rays, "none", n_waves=128)
+    ideal, _ = ds.simulate(rays, "ideal", n_waves=128)
+    assert phases == 1 and ideal <= base
+    # a tick costs at least A clocks and no launch can end before its longest ray
+    assert base >= ds.A * int(rays.max())
+    clocks, left = ds.run_phase(rays, 128, "phased", T=16, R=10 ** 9)
+    assert clocks > 0 and 0 < len(left) < len(rays) and left.min() >= 1
+    total, n_phases = ds.simulate(rays, "phased", T=16, n_waves=128)
+    assert n_phases >= 2 and total > clocks
