@@ -1322,11 +1322,15 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     for (;;) {
         // ---- retire finished rays and hand their lanes new ones, in batches ----
         TL_MARK();
-        const bool done = ray.active && !ray.alive && qsh == 32u;
+        // A lane's ray is alive while t < tmax.  Nothing else says so: a ray that is cut short by
+        // stop_thresh gets tmax = -1 (which finish_ray reads as "stopped"), a lane without a ray
+        // has t = 0, tmax = -1.  (As loop-carried booleans the two cost the scalar unit -- shared
+        // by the CU's four SIMDs -- about sixteen lane-mask copies and merges per march round.)
+        const bool done = ray.active && !(ray.t < ray.tmax) && qsh == 32u;
         const unsigned long long m_done = __builtin_amdgcn_ballot_w64(done);
         const unsigned long long m_free = __builtin_amdgcn_ballot_w64(!ray.active);
         const unsigned long long m_busy =
-            __builtin_amdgcn_ballot_w64(ray.active && (ray.alive || qsh < 32u));
+            __builtin_amdgcn_ballot_w64(ray.active && (ray.t < ray.tmax || qsh < 32u));
         const int n_avail = __builtin_popcountll(m_done | m_free);
         if (COUNT) st_iter++;
         if (n_avail > 0 && (m_busy == 0ull || (!exhausted && n_avail >= p.refill_min))) {
@@ -1339,6 +1343,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
             // composited and stored once everything has landed (their colour state does not
             // overlap the registers the new rays load into).
             uint32_t px_lo = 0, px_hi = 0, fin_xy = 0, fin_frame = 0;
+            ray.stopped = ray.tmax < 0.f;  // (read before a new ray's tmax lands in the register)
             if (done) {
                 const uint32_t* rs = ray_slot(p.ray_buf, wpr, ray_id);
                 px_lo = ray_word(rs, 13);
@@ -1403,10 +1408,13 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     reinterpret_cast<uint8_t*>(((uint64_t)px_hi << 32) | (uint64_t)px_lo), fin_xy,
                     (int)fin_frame);
             if (vacant) {
-                ray.active = ray.alive = ray.entered = take;
+                ray.active = ray.entered = take;
+                if (!take) {  // (no ray: not alive)
+                    ray.t = 0.f;
+                    ray.tmax = -1.f;
+                }
                 ray.out[0] = ray.out[1] = ray.out[2] = ray.out[3] = 0.f;
                 ray.light = 1.f;
-                ray.stopped = false;
                 rc = RayCounters();
                 cur = Cursor();
                 qsh = 32u;
@@ -1421,7 +1429,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         // ---- march: lanes with a live ray and room for another outstanding item ----
         TL_ADD(tl_refill);
         for (int m = 0; m < p.march_max; ++m) {
-            const bool go = ray.active && ray.alive && qsh > 0u;
+            const bool go = ray.t < ray.tmax && qsh > 0u;
             if (!wave_any(go)) break;
             // Guard against rays that never end (not in the reference, which would spin): when
             // the wave has marched kMaxIter rounds without retiring a single ray, whatever is
@@ -1429,8 +1437,8 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
             // round, checked every 1024 rounds.
             if (((++rounds) & 1023u) == 0u && rounds - progress_round >= (uint32_t)kMaxIter) {
                 asm volatile("" ::: "memory");  // keep this a (rarely taken) scalar branch
-                if (ray.active && ray.alive) {
-                    ray.alive = false;
+                if (ray.t < ray.tmax) {
+                    ray.t = ray.tmax;
                     if (p.status) atomicOr(p.status, 1u);
                 }
                 progress_round = rounds;
@@ -1485,12 +1493,10 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     stop = ray.light < p.stop_thresh;
                 }
                 if (stop) {
-                    ray.stopped = true;
-                    ray.alive = false;
+                    ray.tmax = -1.f;  // stopped (and no longer alive)
                     if (COUNT) rc.early++;
                 } else {
                     ray.t += delta_t;
-                    ray.alive = ray.t < ray.tmax;
                 }
             }
             // append this step's items to the ring: k-th pushing lane -> tail + k
@@ -1518,7 +1524,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
             // round costs what a full one costs, so the threshold is a trade: measured below).
             if (p.flush_wait > 0) {
                 const unsigned long long m_wait =
-                    __builtin_amdgcn_ballot_w64(ray.active && !ray.alive && qsh < 32u);
+                    __builtin_amdgcn_ballot_w64(ray.active && !(ray.t < ray.tmax) && qsh < 32u);
                 if (__builtin_popcountll(m_wait) >= p.flush_wait && ring_tail != ring_head) {
                     const uint32_t waiting = ring_tail - ring_head;
                     shade_chunk(waiting < (uint32_t)ST::kShade ? (int)waiting : ST::kShade);
@@ -1527,7 +1533,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         }
         // nobody can march any more (queues full / rays ended): flush what is queued
         // (at most kShade - 1 + 64 items wait here: two rounds at most)
-        while (ring_tail != ring_head && !wave_any(ray.active && ray.alive && qsh > 0u)) {
+        while (ring_tail != ring_head && !wave_any(ray.t < ray.tmax && qsh > 0u)) {
             const uint32_t waiting = ring_tail - ring_head;
             shade_chunk(waiting < (uint32_t)ST::kShade ? (int)waiting : ST::kShade);
         }
