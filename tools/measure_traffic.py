@@ -49,6 +49,11 @@ GROUPS = {
     "tcp1": "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum",
     "tcp2": "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum "
             "TCP_TCC_READ_REQ_LATENCY_sum",
+    "tcp3": "TCP_TOTAL_ACCESSES_sum TCP_TOTAL_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum "
+            "TCP_TCR_TCP_STALL_CYCLES_sum",
+    "tcp4": "TCP_TCP_LATENCY_sum TCP_RFIFO_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum TCP_TCR_RDRET_STALL_sum",
+    "sq3": "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH",
+    "sq4": "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_WAIT_INST_LDS",
     # TA_* and TD_* counters abort rocprofv3 on this pool (measured twice in round 1): not offered
 }
 SOURCES = ["volrend_amd/csrc/vr_kernels.hip", "volrend_amd/csrc/vr_device_math.h",

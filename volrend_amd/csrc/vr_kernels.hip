@@ -237,12 +237,6 @@ __device__ unsigned long long vr_tl3[kTl3Copies][kTl3Rows][kTl3Buckets];
 #ifndef VR_MS_SH9_WAVES
 #define VR_MS_SH9_WAVES 8
 #endif
-#ifndef VR_DIAG_SERIAL
-#define VR_DIAG_SERIAL 0      // diagnostic builds: bit 0 / bit 1 = an extra wait behind the march / refill requests
-#endif
-#ifndef VR_LOOKUP_RETRY
-#define VR_LOOKUP_RETRY 0     // fused kernel: one lookup word per lane and round (see the march requests)
-#endif
 #ifndef VR_PACKED_EXP
 #define VR_PACKED_EXP 1       // the sigmoids of channels 0/1 share packed mul / fma / add instructions
 #endif
@@ -476,75 +470,6 @@ __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* 
         } else {
             // deeper than the brick: one child word per level (32-bit byte offsets: the node
             // array is < 4 GB, checked at upload)
-            const char* nodes_base = reinterpret_cast<const char*>(p.nodes);
-            uint32_t node = w, slot;
-            int l = (int)(g0 + bl);
-            for (;; ++l) {
-                const uint32_t sh = (uint32_t)(23 - l);
-                slot = (__builtin_amdgcn_ubfe(ux, sh, 1u) << 2) |
-                       (__builtin_amdgcn_ubfe(uy, sh, 1u) << 1) | __builtin_amdgcn_ubfe(uz, sh, 1u);
-                w = *reinterpret_cast<const uint32_t*>(nodes_base + (node * 8u + slot) * 4u);
-                if (COUNT) touch(p, TOUCH_NODES, (uint64_t)(node * 8u + slot) * 4u, 4u);
-                if ((w & kLeafBit) || l >= 23) break;
-                node = w;
-            }
-            d = l + 1;
-            id = node * 8u + slot;
-        }
-    }
-    *depth = d;
-    *word = w;
-    const float cs = u2f((uint32_t)(127 + d) << 23);  // 2^d
-    xyz[0] = __builtin_amdgcn_fractf(xyz[0] * cs);
-    xyz[1] = __builtin_amdgcn_fractf(xyz[1] * cs);
-    xyz[2] = __builtin_amdgcn_fractf(xyz[2] * cs);
-    return id;
-}
-
-// query_n2 in three steps, for the pipelined render kernel: a sample asks for ONE lookup word per
-// round (the entry of a new top cell, or the brick entry of the cell it is still in) and is
-// resolved once that word is there.  Same digits, same tables, same bits as query_n2.
-// (1) clamp + fixed point + top cell index; u[] = floor(xyz * 2^24)
-__device__ __forceinline__ uint32_t lookup_cell(const KParams& p, float* xyz, uint32_t* u) {
-    const float hi = 1.f - 1e-6f;  // one v_med3_f32 per axis: see query_n2
-    xyz[0] = __builtin_amdgcn_fmed3f(xyz[0], 0.f, hi);
-    xyz[1] = __builtin_amdgcn_fmed3f(xyz[1], 0.f, hi);
-    xyz[2] = __builtin_amdgcn_fmed3f(xyz[2], 0.f, hi);
-    u[0] = (uint32_t)(xyz[0] * 16777216.f);
-    u[1] = (uint32_t)(xyz[1] * 16777216.f);
-    u[2] = (uint32_t)(xyz[2] * 16777216.f);
-    const uint32_t g0 = (uint32_t)p.top_levels, sh0 = 24u - g0;
-    return ((((u[0] >> sh0) << g0) | (u[1] >> sh0)) << g0) | (u[2] >> sh0);
-}
-// (2) index of the brick entry of a sample inside the internal top cell with entry word e0
-__device__ __forceinline__ uint32_t brick_entry(const KParams& p, uint32_t e0, const uint32_t* u) {
-    const uint32_t g0 = (uint32_t)p.top_levels, bl = (uint32_t)p.brick_levels, sh1 = 24u - g0 - bl;
-    const uint32_t sub = (((__builtin_amdgcn_ubfe(u[0], sh1, bl) << bl) |
-                           __builtin_amdgcn_ubfe(u[1], sh1, bl)) << bl) |
-                         __builtin_amdgcn_ubfe(u[2], sh1, bl);
-    return (e0 << (3u * bl)) + sub;
-}
-// (3) the leaf from the top entry in `cur` and -- internal cells -- the brick entry `bw`;
-// xyz (clamped by lookup_cell) is rewritten to leaf-local coordinates
-template <bool COUNT>
-__device__ __forceinline__ uint32_t resolve_n2(const KParams& p, float* xyz, const Cursor& cur,
-                                               uint32_t bw, int* depth, uint32_t* word) {
-    uint32_t w = cur.e0, id = cur.e1;
-    int d;
-    if (w & kLeafBit) {
-        d = (int)__builtin_amdgcn_ubfe(w, 16u, 5u);
-    } else {
-        const uint32_t g0 = (uint32_t)p.top_levels, bl = (uint32_t)p.brick_levels;
-        w = bw;
-        if (w & kLeafBit) {
-            d = (int)(g0 + 1u + __builtin_amdgcn_ubfe(w, 29u, 2u));
-            id = (id << 3) + __builtin_amdgcn_ubfe(w, 16u, 13u);  // (root + delta) * 8 + slot
-        } else {
-            // deeper than the brick (rare: trees of more than G0 + BL levels): one child word per
-            // level, waited for in place (32-bit byte offsets: the node array is < 4 GB, upload)
-            const uint32_t ux = (uint32_t)(xyz[0] * 16777216.f);
-            const uint32_t uy = (uint32_t)(xyz[1] * 16777216.f);
-            const uint32_t uz = (uint32_t)(xyz[2] * 16777216.f);
             const char* nodes_base = reinterpret_cast<const char*>(p.nodes);
             uint32_t node = w, slot;
             int l = (int)(g0 + bl);
@@ -1064,8 +989,8 @@ __device__ __forceinline__ void finish_ray(const KParams& p, Ray& ray, const Ray
 // Wave-private LDS of the march kernel (one wave per workgroup):
 //   ring  : colour work items (leaf, weight, owner lane) in sample order
 //   stage : the SH records of one shade round, DMA'd straight from HBM (global_load_lds)
-//   res   : the three colour contributions of each item of the round (+ the item's weight, RGBA
-//           format) -- aliases the first 1024 bytes of `stage`: every row has been consumed by then
+//   res   : the three colour contributions of each item of the round (aliases the first
+//           768 bytes of `stage`: every row has been consumed by then)
 // The basis of a lane's ray lives in that lane's registers; the lane that shades one of its
 // items reads it through the LDS crossbar (ds_bpermute).
 // ---------------------------------------------------------------------------
@@ -1157,7 +1082,7 @@ struct Stage {
     static constexpr int kPasses = (BASIS == BASIS_25) ? 2 : 1;
     static constexpr int kShade = kPass * kPasses;                    // items per shade round
     static constexpr int kInstr = (kPass + kPerInstr - 1) / kPerInstr;
-    static constexpr int kBytes = (kEnabled && kPass * kRow > 1024) ? kPass * kRow : 1024;
+    static constexpr int kBytes = (kEnabled && kPass * kRow > 768) ? kPass * kRow : 768;
 };
 typedef __attribute__((address_space(1))) const void* vr_gptr_t;
 typedef __attribute__((address_space(3))) void* vr_lptr_t;
@@ -1166,14 +1091,6 @@ typedef __attribute__((address_space(3))) void* vr_lptr_t;
 // only moves qsh).  (Eight per ray, measured: -2 % on a lone 20-frame launch, nothing on a
 // 64-frame one, for a second register and a 64-bit funnel shift per push.)
 constexpr int kOwnerQ = 4;
-// Ring capacity of the fused kernel.  A one-pass flavour frees the entries of a shade round when
-// the round's record requests go out, so a round's pushes find at most 63 entries in use: 128.
-// The two-pass flavour (SH25) reads the leaf ids again for its second pass and frees the entries
-// after the round: at most 127 + 64 in use, 256.
-template <int BASIS>
-constexpr int ring_size() {
-    return Stage<BASIS>::kPasses > 1 ? 256 : kRing;
-}
 
 // The record requests of one pass of a shade round (see Stage): lane l fetches 16-byte chunk
 // l % V of record l / V of its instruction, straight into the stage rows.  NT = the non-temporal
@@ -1182,19 +1099,12 @@ template <int BASIS, bool NT, int RING = kRing>
 __device__ __forceinline__ void issue_records(const KParams& p, char* stage, const uint32_t* it_leaf,
                                               uint32_t ring_head, int lane, int n, int pass) {
     using ST = Stage<BASIS>;
-    // (all leaf ids first, then the requests: one LDS round trip for the pass, not one per instruction)
-    uint32_t leaves[ST::kInstr];
-#pragma unroll
-    for (int k = 0; k < ST::kInstr; ++k) {
-        const int item = pass * ST::kPass + k * ST::kPerInstr + lane / ST::kVec;
-        leaves[k] = it_leaf[(ring_head + (uint32_t)item) & (RING - 1)];  // (any lane: a valid LDS address)
-    }
 #pragma unroll
     for (int k = 0; k < ST::kInstr; ++k) {
         const int rin = k * ST::kPerInstr + lane / ST::kVec;  // record within the pass
         const int item = pass * ST::kPass + rin;
         if (lane < ST::kPerInstr * ST::kVec && rin < ST::kPass && item < n) {
-            const uint32_t leaf = VR_EXP_RECORD_LEAF(leaves[k]);
+            const uint32_t leaf = VR_EXP_RECORD_LEAF(it_leaf[(ring_head + (uint32_t)item) & (RING - 1)]);
             const char* src = reinterpret_cast<const char*>(p.leaves) +
                               (uint64_t)leaf * (uint32_t)(p.leaf_stride_h * 2) + (lane % ST::kVec) * 16;
             // (the LDS address is formed in address space 3: a generic-pointer detour between two
@@ -1222,44 +1132,35 @@ constexpr int min_waves_per_eu() {
 // Waves one CU holds of a flavour: the register bound above or the LDS bound (512-byte granules).
 template <int BASIS, int MODE>
 constexpr int waves_per_cu() {
-    const int lds = ((ring_size<BASIS>() * 9 + Stage<BASIS>::kBytes + 511) / 512) * 512;
+    const int lds = ((kRing * 9 + Stage<BASIS>::kBytes + 511) / 512) * 512;
     const int by_lds = 163840 / lds, by_reg = 4 * min_waves_per_eu<BASIS, MODE>();
     return by_lds < by_reg ? by_lds : by_reg;
 }
-
-constexpr uint32_t kNoRay = 0xFFFFFFFFu;  // ray_id of a lane that holds no ray
 
 template <int FMA, int BASIS, int MODE>
 __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void render_kernel(
     const KParams p) {
     using P = Policy<FMA>;
     constexpr bool N2 = MODE != MODE_GENERIC;
+    constexpr bool LOBES = MODE != MODE_FAST;
     constexpr bool COUNT = MODE != MODE_FAST;
     constexpr int NB = BASIS > 1 ? BASIS : 1;
     constexpr bool HAS_BASIS = BASIS != BASIS_RGBA;
     using ST = Stage<BASIS>;
-    constexpr int RING = ring_size<BASIS>();
-    // one-pass flavours free the ring entries of a shade round when its record requests go out
-    // (see ring_size): the weight and the owner of the lane's item wait in two registers
-    constexpr bool EARLY_FREE = ST::kPasses == 1;
-    __shared__ uint32_t it_leaf[RING];
-    __shared__ float it_w[RING];
-    __shared__ uint8_t it_own[RING];
+    __shared__ uint32_t it_leaf[kRing];
+    __shared__ float it_w[kRing];
+    __shared__ uint8_t it_own[kRing];
     __shared__ __attribute__((aligned(16))) char stage[ST::kBytes];
-    float* const res = reinterpret_cast<float*>(stage);  // 4 x 64 floats, see above
+    float* const res = reinterpret_cast<float*>(stage);  // 3 x 64 floats, see above
     float mybasis[NB];  // basis_fn of this lane's ray (rt_core.cuh:96-103), read by shader lanes
 #pragma unroll
     for (int i = 0; i < NB; ++i) mybasis[i] = 0.f;
 
     const int lane = threadIdx.x & (kWave - 1);
     Ray ray;
-    ray.active = ray.alive = ray.stopped = false;
-    ray.entered = true;  // (every ray of the buffer passed the ray/box test: raygen_kernel)
-    uint32_t ray_id = kNoRay;  // index of the lane's ray in the ray buffer
-    // A lane's ray is alive while t < tmax.  Nothing else says so: a ray that is cut short by
-    // stop_thresh gets tmax = -1 (which the retire path reads as "stopped"), a lane without a ray
-    // has t = 0, tmax = -1.  (As loop-carried booleans the two cost the scalar unit -- shared by
-    // the CU's four SIMDs -- about sixteen lane-mask copies and merges per round.)
+    ray.active = false;
+    ray.alive = ray.entered = ray.stopped = false;
+    uint32_t ray_id = 0;  // index of the lane's ray in the ray buffer
     ray.t = 0.f;
     ray.tmax = -1.f;
     ray.light = 1.f;
@@ -1275,7 +1176,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     Cursor cur;
     uint32_t qpos = 0;  // ring positions of this ray's outstanding items, see kOwnerQ
     uint32_t qsh = 32;  // 32 - 8 * (number of outstanding items)
-    uint32_t rounds = 0, progress_round = 0;  // rounds of this wave; the last one with a retire
+    uint32_t rounds = 0, progress_round = 0;  // march rounds of this wave; the last one before a retire
     // wave-uniform scheduler state
     bool exhausted = false;  // the ray buffer has been handed out completely
     uint32_t chunk_next = 0, chunk_end = 0;  // this wave's private range of ray ids
@@ -1288,122 +1189,161 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
 
     TL_DECL_FUSED();
     TL3_DECL();
+    // Colour evaluation of up to 64 queued items, one per lane, whoever owns them;
+    // afterwards every owner adds the contributions of its own items, oldest first
+    // (= the reference's accumulation order, rt_core.cuh:161).
+    auto shade_chunk = [&](int n) {
+        TL_ADD(tl_march);
+        TL3_SHADE(n);
+        __syncthreads();  // item pushes are visible
+        if (COUNT) {
+            st_shade_r++;
+            st_shade_l += (uint32_t)n;
+            // distinct leaves among the chunk's items (instrumentation only)
+            const uint32_t myleaf =
+                lane < n ? it_leaf[(ring_head + (uint32_t)lane) & (kRing - 1)] : 0xFFFFFFFFu;
+            bool first = lane < n;
+            for (int o = 0; o < kWave; ++o) {
+                const uint32_t other = (uint32_t)__shfl((int)myleaf, o);
+                if (o < lane && other == myleaf) first = false;
+            }
+            st_distinct += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(first));
+            if (lane < n)  // the record this item reads (colour coefficients only: sigma rides in the node word)
+                touch(p, TOUCH_LEAVES, (uint64_t)myleaf * (uint32_t)(p.leaf_stride_h * 2),
+                      (uint32_t)(2 * (p.data_dim - 1)));
+        }
+        const bool have = lane < n;
+        const uint32_t jmine = (ring_head + (uint32_t)lane) & (kRing - 1);
+        const float weight = have ? it_w[jmine] : 0.f;
+        // basis_fn[i] of the ray that owns my item, out of its lane's registers through the LDS
+        // crossbar (every lane executes the permute: a bpermute only reads active lanes)
+        const int own4 = (HAS_BASIS && have) ? (int)it_own[jmine] << 2 : lane << 2;
+        auto basis_of = [&](int i) -> float {
+            return u2f((uint32_t)__builtin_amdgcn_ds_bpermute(own4, (int)f2u(mybasis[i])));
+        };
+        // One-pass flavours fetch each group of basis values right where the (whole) wave uses
+        // it; the two-pass flavour (SH25) computes with half the wave at a time, so it gathers
+        // everything up front while every owner lane is still active.
+        float bfull[ST::kPasses > 1 ? NB : 1];
+        if constexpr (ST::kPasses > 1) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) bfull[i] = basis_of(i);
+        }
+        auto basis_get = [&](int i) -> float {
+            if constexpr (ST::kPasses > 1) return bfull[i];
+            else return basis_of(i);
+        };
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        if constexpr (ST::kEnabled) {
+#pragma unroll
+            for (int pass = 0; pass < ST::kPasses; ++pass) {
+                if (pass * ST::kPass < n) {  // wave-uniform
+                    // Cache policy of the record stream (launch-uniform, chosen at upload): by
+                    // default the records allocate in L2 like any load -- neighbouring rays
+                    // re-use a quarter of them; when the lookup structure is much larger than
+                    // the L2s, the stream is marked non-temporal so that it stops evicting the
+                    // top / brick lines every sample needs (C3: -11 % time; C1-class trees:
+                    // +8 %, hence the switch).  The policy is an immediate of the instruction,
+                    // so the issue loop exists twice.
+                    if (p.records_nt)
+                        issue_records<BASIS, true>(p, stage, it_leaf, ring_head, lane, n, pass);
+                    else
+                        issue_records<BASIS, false>(p, stage, it_leaf, ring_head, lane, n, pass);
+                    __syncthreads();  // the DMAs have landed (vmcnt(0)) and are visible
+                    TL_ADD(tl_shade_load);
+                    // (one pass: ALL lanes run the arithmetic -- an owner lane without an item
+                    // of its own must stay active for the permutes; only `have` lanes keep results)
+                    if (ST::kPasses == 1 || lane / ST::kPass == pass) {
+                        const char* row = stage + (lane % ST::kPass) * ST::kRow;
+                        float acc[3];
+                        channel_sums<FMA, BASIS, (VR_SHADE_SCHED_BARRIER != 0) || (BASIS == 25 && VR_SH25_WAVES >= 5)>(row, basis_get, acc);
+                        // rt_core.cuh:161: weight / (1 + expf(-tmp)) per channel
+                        if constexpr (VR_PACKED_EXP) {
+                            const float2v e01 = vr_expf2((float2v){-acc[0], -acc[1]}) + splat2(1.f);
+                            r0 = weight / e01.x;
+                            r1 = weight / e01.y;
+                        } else {
+                            r0 = weight / (1.f + vr_expf(-acc[0]));
+                            r1 = weight / (1.f + vr_expf(-acc[1]));
+                        }
+                        r2 = weight / (1.f + vr_expf(-acc[2]));
+                    }
+                    if (ST::kPasses > 1) __syncthreads();  // rows are free for the next pass
+                    TL_ADD(tl_shade_math);
+                }
+            }
+        } else {
+          const float b0 = HAS_BASIS ? basis_of(0) : 0.f;  // (every lane: see above)
+          if (have) {
+            Record<BASIS> rec;
+            load_record<BASIS>(p, it_leaf[jmine], rec);
+            if (HAS_BASIS) {  // runtime basis size: first coefficient of each channel only
+                r0 = weight / (1.f + vr_expf(-(b0 * rec.at(0))));
+                r1 = weight / (1.f + vr_expf(-(b0 * rec.at(1))));
+                r2 = weight / (1.f + vr_expf(-(b0 * rec.at(2))));
+            } else {  // RGBA: out[c] = madd(colour, weight, out[c]) is formed by the owner
+                r0 = rec.at(0);
+                r1 = rec.at(1);
+                r2 = rec.at(2);
+            }
+          }
+        }
+        __syncthreads();  // every row has been read: `res` may overwrite them
+        if (have) {
+            res[0 * kWave + lane] = r0;
+            res[1 * kWave + lane] = r1;
+            res[2 * kWave + lane] = r2;
+        }
+        __syncthreads();  // contributions are visible
+        TL_ADD(tl_shade_math);
+        const uint32_t head8 = ring_head & 0xFFu;
+#pragma unroll
+        for (int d = 0; d < kOwnerQ; ++d) {
+            const uint32_t pos = __builtin_amdgcn_ubfe(qpos, qsh, 8u);  // my oldest item
+            const uint32_t idx = (pos - head8) & 0xFFu;               // its index within the round
+            if (qsh < 32u && idx < (uint32_t)n) {
+                if (HAS_BASIS) {
+                    ray.out[0] += res[0 * kWave + idx];
+                    ray.out[1] += res[1 * kWave + idx];
+                    ray.out[2] += res[2 * kWave + idx];
+                } else {
+                    const float w = it_w[pos & (kRing - 1)];
+                    ray.out[0] = P::madd(res[0 * kWave + idx], w, ray.out[0]);
+                    ray.out[1] = P::madd(res[1 * kWave + idx], w, ray.out[1]);
+                    ray.out[2] = P::madd(res[2 * kWave + idx], w, ray.out[2]);
+                }
+                qsh += 8u;
+            }
+        }
+        ring_head += (uint32_t)n;
+        TL_ADD(tl_shade_acc);
+    };
 
     for (;;) {
+        // ---- retire finished rays and hand their lanes new ones, in batches ----
         TL_MARK();
-        // Guard against rays that never end (not in the reference, which would spin): when the
-        // wave has gone kMaxIter rounds without retiring a single ray, whatever is still
-        // marching is cut and reported.  Wave-uniform state only, checked every 1024 rounds.
-        if (((++rounds) & 1023u) == 0u && rounds - progress_round >= (uint32_t)kMaxIter) {
-            asm volatile("" ::: "memory");  // keep this a (rarely taken) scalar branch
-            if (ray.t < ray.tmax) {
-                ray.t = ray.tmax;
-                if (p.status) atomicOr(p.status, 1u);
-            }
-            progress_round = rounds;
-        }
-        // ---- who does what in this round ----
-        const bool alive = ray.t < ray.tmax;
-        const bool go = alive && qsh != 0u;        // takes a sample: room for one more colour item
-        const bool vacant = !alive && qsh == 32u;  // ray over and every colour landed, or no ray
-        const unsigned long long m_go = __builtin_amdgcn_ballot_w64(go);
-        const unsigned long long m_vac = __builtin_amdgcn_ballot_w64(vacant);
-        const int n_vac = __builtin_popcountll(m_vac);
-        // Retire + refill: as soon as refill_min lanes are vacant (the round trip is shared with
-        // the march, so batches may be small), or when nothing else is left to do.
-        const bool refill =
-            n_vac > 0 && (m_vac == ~0ull || (!exhausted && n_vac >= p.refill_min));
+        // A lane's ray is alive while t < tmax.  Nothing else says so: a ray that is cut short by
+        // stop_thresh gets tmax = -1 (which finish_ray reads as "stopped"), a lane without a ray
+        // has t = 0, tmax = -1.  (As loop-carried booleans the two cost the scalar unit -- shared
+        // by the CU's four SIMDs -- about sixteen lane-mask copies and merges per march round.)
+        const bool done = ray.active && !(ray.t < ray.tmax) && qsh == 32u;
+        const unsigned long long m_done = __builtin_amdgcn_ballot_w64(done);
+        const unsigned long long m_free = __builtin_amdgcn_ballot_w64(!ray.active);
+        const unsigned long long m_busy =
+            __builtin_amdgcn_ballot_w64(ray.active && (ray.t < ray.tmax || qsh < 32u));
+        const int n_avail = __builtin_popcountll(m_done | m_free);
         if (COUNT) st_iter++;
-
-        // ================= requests: everything this round needs from memory =================
-        // ---- (A) march: the lookup word the lane's sample is waiting for ----
-        float pos[3] = {0.f, 0.f, 0.f};
-        bool have = false;  // the entry of the sample's top cell is in the cursor
-        uint32_t bw;        // brick entry of the sample (internal top cells; only read by the lanes that load it)
-#if VR_LOOKUP_RETRY
-        // Variant: ONE lookup word per lane and round.  A lane that enters a new top cell asks for
-        // the cell's entry and, if that turns out to be an internal node, for the brick entry in
-        // the NEXT round (its sample takes two rounds), so that a round of the wave costs one
-        // memory latency instead of two.  ne0 / ne1: the entry of the new cell -- it lands in
-        // registers of its own and moves into the cursor after the wait (a register with a load
-        // in flight stalls every lane that reads OR writes it: hence no cursor registers as load
-        // targets and no initial values).  Measured slower (profiles/r04_experiments.jsonl): the
-        // repeated rounds cost more than the shorter round buys.
-        uint32_t ne0, ne1;
-        bool newcell = false;
-        if (N2 && go) {
-            pos[0] = P::madd(ray.t, ray.dir[0], ray.cen[0]);
-            pos[1] = P::madd(ray.t, ray.dir[1], ray.cen[1]);
-            pos[2] = P::madd(ray.t, ray.dir[2], ray.cen[2]);
-            uint32_t u[3];
-            const uint32_t cell = lookup_cell(p, pos, u);
-            if (cell != cur.cell) {
-                const uint2 e = *reinterpret_cast<const uint2*>(
-                    reinterpret_cast<const char*>(p.top) + (cell << 3));
-                if (COUNT) touch(p, TOUCH_TOP, (uint64_t)cell * 8u, 8u);
-                cur.cell = cell;
-                ne0 = e.x;
-                ne1 = e.y;
-                newcell = true;
-            } else {
-                have = true;
-                if (!(cur.e0 & kLeafBit)) {
-                    const uint32_t entry = brick_entry(p, cur.e0, u);
-                    if (COUNT) touch(p, TOUCH_BRICKS, (uint64_t)entry * 4u, 4u);
-                    bw = *reinterpret_cast<const uint32_t*>(
-                        reinterpret_cast<const char*>(p.bricks) + (entry << 2));
-                }
+        if (n_avail > 0 && (m_busy == 0ull || (!exhausted && n_avail >= p.refill_min))) {
+            if (COUNT && m_done != 0ull) {
+                st_fin_r++;
+                st_fin_l += (uint32_t)__builtin_popcountll(m_done);
             }
-        }
-#else
-        // N == 2 lookup structure (query_n2's first half): the entry of the sample's top cell --
-        // loaded and waited for right here when the ray has left the cell of its last sample
-        // (top is L2-resident: a short latency) -- and the request for the brick entry, which
-        // then travels together with the ray words and the record DMAs below.
-        if (N2 && go) {
-            pos[0] = P::madd(ray.t, ray.dir[0], ray.cen[0]);
-            pos[1] = P::madd(ray.t, ray.dir[1], ray.cen[1]);
-            pos[2] = P::madd(ray.t, ray.dir[2], ray.cen[2]);
-            uint32_t u[3];
-            const uint32_t cell = lookup_cell(p, pos, u);
-            if (cell != cur.cell) {
-                // 32-bit byte offsets from a uniform base (top: <= 128 MB; bricks: < 4 GB, upload)
-                const uint2 e = *reinterpret_cast<const uint2*>(
-                    reinterpret_cast<const char*>(p.top) + (cell << 3));
-                if (COUNT) touch(p, TOUCH_TOP, (uint64_t)cell * 8u, 8u);
-                cur.cell = cell;
-                cur.e0 = e.x;
-                cur.e1 = e.y;
-            }
-            have = true;
-            if (!(cur.e0 & kLeafBit)) {
-                const uint32_t entry = brick_entry(p, cur.e0, u);
-                if (COUNT) touch(p, TOUCH_BRICKS, (uint64_t)entry * 4u, 4u);
-                bw = *reinterpret_cast<const uint32_t*>(
-                    reinterpret_cast<const char*>(p.bricks) + (entry << 2));
-            }
-        }
-#endif
-
-#if VR_DIAG_SERIAL & 1
-        __syncthreads();  // (diagnostic build: the lookup words land before anything else is requested)
-#endif
-        // ---- (C) retire + refill: pixel addresses of the finished rays, the next rays ----
-        // The new rays load straight into the registers of the vacant lanes; the finished rays
-        // are composited and stored below, once everything has landed (their colour state does
-        // not overlap the registers the new rays load into).
-        uint32_t px_lo = 0, px_hi = 0, fin_xy = 0, fin_frame = 0;
-        bool take = false, stopped = false;
-        const bool done = vacant && ray_id != kNoRay;
-        if (refill) {
-            if (COUNT) {
-                const unsigned long long m_done = __builtin_amdgcn_ballot_w64(done);
-                if (m_done != 0ull) {
-                    st_fin_r++;
-                    st_fin_l += (uint32_t)__builtin_popcountll(m_done);
-                }
-            }
-            stopped = ray.tmax < 0.f;  // (read before a new ray's tmax lands in the register)
+            // The whole round costs ONE memory round trip: the pixel address of every finished
+            // ray is requested here, the new rays right behind it, and the finished rays are
+            // composited and stored once everything has landed (their colour state does not
+            // overlap the registers the new rays load into).
+            uint32_t px_lo = 0, px_hi = 0, fin_xy = 0, fin_frame = 0;
+            ray.stopped = ray.tmax < 0.f;  // (read before a new ray's tmax lands in the register)
             if (done) {
                 const uint32_t* rs = ray_slot(p.ray_buf, wpr, ray_id);
                 px_lo = ray_word(rs, 13);
@@ -1413,12 +1353,14 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     fin_frame = ray_word(rs, 15);
                 }
             }
+            const bool vacant = done || !ray.active;
+            bool take = false;
             progress_round = rounds;
-            // Vacant lanes take consecutive rays from the buffer.  The wave owns a private chunk
-            // [chunk_next, chunk_end) of ray ids and only goes to the global queue head (ONE
-            // returning atomic -- a single word sustains ~90 of them per microsecond chip-wide)
-            // when the chunk is used up; chunk sizes shrink as the queue drains (guided
-            // self-scheduling) so the tail stays balanced.
+            // Idle lanes take consecutive rays from the buffer.  The wave owns a private
+            // chunk [chunk_next, chunk_end) of ray ids and only goes to the global queue
+            // head (ONE returning atomic -- a single word sustains ~90 of them per
+            // microsecond chip-wide) when the chunk is used up; chunk sizes shrink as the
+            // queue drains (guided self-scheduling) so the tail stays balanced.
             if (!exhausted && chunk_next >= chunk_end) {
                 uint32_t lo, hi;
                 grab_chunk(p, total, lane, lo, hi);
@@ -1433,12 +1375,13 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 }
             }
             if (!exhausted) {
+                const unsigned long long idle = m_done | m_free;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
-                    (uint32_t)(m_vac >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_vac, 0u));
+                    (uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const uint32_t r = chunk_next + rank;
                 const uint32_t c_end = chunk_end;
                 const uint32_t left = chunk_end - chunk_next;
-                chunk_next += (uint32_t)n_vac < left ? (uint32_t)n_vac : left;
+                chunk_next += (uint32_t)n_avail < left ? (uint32_t)n_avail : left;
                 if (vacant && r < c_end) {
                     take = true;
                     const uint32_t* rs = ray_slot(p.ray_buf, wpr, r);
@@ -1459,175 +1402,16 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     }
                 }
             }
-        }
-
-#if VR_DIAG_SERIAL & 2
-        __syncthreads();  // (diagnostic build: the ray words land before the records are requested)
-#endif
-        // ---- (B) shade: the SH records of the next 64 queued colour items ----
-        // (or of whatever is queued when nobody can march any more: rays ended / queues full)
-        const uint32_t waiting = ring_tail - ring_head;
-        int n_sh = 0;
-        if (waiting >= (uint32_t)ST::kShade) {
-            n_sh = ST::kShade;
-        } else if (waiting != 0u) {
-            bool flush = m_go == 0ull;
-            // Lanes whose ray has ended but still has colour items queued can neither march nor
-            // be refilled: once flush_wait of them idle, a partial shade round frees them (the
-            // round costs what a full one costs, so the threshold is a trade; default off).
-            if (!flush && p.flush_wait > 0) {
-                const unsigned long long m_wait = __builtin_amdgcn_ballot_w64(!alive && qsh < 32u);
-                flush = __builtin_popcountll(m_wait) >= p.flush_wait;
-            }
-            if (flush) n_sh = (int)waiting;
-        }
-        const uint32_t sh_head = ring_head;  // first item of the round
-        const bool have_item = lane < n_sh;
-        float sh_weight = 0.f;
-        int sh_own4 = lane << 2;
-        Record<ST::kEnabled ? BASIS_RGBA : BASIS> rec;  // small records travel through registers
-        if (n_sh > 0) {
-            const uint32_t jmine = (sh_head + (uint32_t)lane) & (RING - 1);
-            if (COUNT) {
-                st_shade_r++;
-                st_shade_l += (uint32_t)n_sh;
-                // distinct leaves among the round's items (instrumentation only)
-                const uint32_t myleaf = have_item ? it_leaf[jmine] : 0xFFFFFFFFu;
-                bool first = have_item;
-                for (int o = 0; o < kWave; ++o) {
-                    const uint32_t other = (uint32_t)__shfl((int)myleaf, o);
-                    if (o < lane && other == myleaf) first = false;
-                }
-                st_distinct += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(first));
-                if (have_item)  // the record this item reads (colour coefficients only: sigma rides in the node word)
-                    touch(p, TOUCH_LEAVES, (uint64_t)myleaf * (uint32_t)(p.leaf_stride_h * 2),
-                          (uint32_t)(2 * (p.data_dim - 1)));
-            }
-            if (EARLY_FREE) {
-                sh_weight = have_item ? it_w[jmine] : 0.f;
-                if (HAS_BASIS && have_item) sh_own4 = (int)it_own[jmine] << 2;
-            }
-            if constexpr (ST::kEnabled) {
-                // Cache policy of the record stream (launch-uniform, chosen at upload): by default
-                // the records allocate in L2 like any load -- neighbouring rays re-use a quarter
-                // of them; when the lookup structure is much larger than the L2s, the stream is
-                // marked non-temporal so that it stops evicting the top / brick lines every
-                // sample needs (C3: -11 % time; C1-class trees: +8 %, hence the switch).  The
-                // policy is an immediate of the instruction, so the issue loop exists twice.
-                if (p.records_nt)
-                    issue_records<BASIS, true, RING>(p, stage, it_leaf, sh_head, lane, n_sh, 0);
-                else
-                    issue_records<BASIS, false, RING>(p, stage, it_leaf, sh_head, lane, n_sh, 0);
-            } else {
-                if (have_item) load_record<ST::kEnabled ? BASIS_RGBA : BASIS>(p, it_leaf[jmine], rec);
-            }
-            if (EARLY_FREE) ring_head += (uint32_t)n_sh;
-        }
-        TL_ADD(tl_march);
-
-        // ================= the ONE wait of the round =================
-        // lookup words, ray words and record DMAs have all landed (vmcnt(0)) and are visible
-        __syncthreads();
-        TL_ADD(tl_shade_load);
-
-        // ================= (A') the samples whose lookup is complete =================
-        // rt_core.cuh:108-188 without the colour arithmetic
-#if VR_LOOKUP_RETRY
-        if (N2 && newcell) {
-            cur.e0 = ne0;
-            cur.e1 = ne1;
-        }
-#endif
-        bool ready = go;
-        if (N2 && VR_LOOKUP_RETRY) ready = go && (have || (cur.e0 & kLeafBit) != 0u);
-        if (COUNT) {
-            st_march_r++;
-            st_march_l += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ready));
-        }
-        TL3_ROUND(ready);
-        bool push = false;
-        uint32_t leaf = 0;
-        float weight = 0.f;
-        if (ready) {
-            float cube_sz = 0.f;
-            int levels;
-            uint32_t word;
-            if (N2) {
-                leaf = resolve_n2<COUNT>(p, pos, cur, bw, &levels, &word);
-            } else {
-                pos[0] = P::madd(ray.t, ray.dir[0], ray.cen[0]);
-                pos[1] = P::madd(ray.t, ray.dir[1], ray.cen[1]);
-                pos[2] = P::madd(ray.t, ray.dir[2], ray.cen[2]);
-                leaf = (uint32_t)query_generic<FMA, COUNT>(p, pos, &cube_sz, &levels, &word);
-            }
-            if (COUNT) {
-                rc.samples++;
-                rc.child_reads += (uint32_t)levels;
-            }
-            // rt_core.cuh:116: dda / cube_sz
-            const float dda = dda_unit<FMA>(pos, ray.invdir);
-            // N2: cube_sz = 2^levels; x / 2^k == ldexp(x, -k), the same real number rounded once
-            const float t_subcube = N2 ? __builtin_amdgcn_ldexpf(dda, -levels) : dda / cube_sz;
-            const float delta_t = t_subcube + p.step_size;
-            const float sigma = h2f((uint16_t)(word & 0xFFFFu));
-            bool stop = false;
-            if (sigma > p.sigma_thresh) {
-                // rt_core.cuh:118-121,174: attenuation, weight and the light update are taken
-                // now; the colour of this sample -- which nothing else depends on -- becomes a
-                // work item for the shade phase.
-                if (COUNT) rc.hits++;
-                const float att = vr_expf(-delta_t * ray.delta_scale * sigma);
-                weight = ray.light * (1.f - att);
-                if (COUNT && p.render_depth)  // (depth launches take the FULL flavour)
-                    ray.out[0] = P::madd(weight, ray.t, ray.out[0]);
-                else if (VR_EXP_FUSED_COLOUR)
-                    push = true;
-                else
-                    ray.out[1] += weight;
-                ray.light *= att;
-                stop = ray.light < p.stop_thresh;
-            }
-            if (stop) {
-                ray.tmax = -1.f;  // stopped (and no longer alive)
-                if (COUNT) rc.early++;
-            } else {
-                ray.t += delta_t;
-            }
-        }
-        // append this round's items to the ring: k-th pushing lane -> tail + k.  (Room: a one-pass
-        // flavour enters here with at most 63 items queued, the two-pass flavour with at most 127
-        // of 256 entries in use.)
-        const unsigned long long m_push = __builtin_amdgcn_ballot_w64(push);
-        if (m_push != 0ull) {
-            if (push) {
-                const uint32_t seq =
-                    ring_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_push >> 32),
-                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)m_push, 0u));
-                const uint32_t j = seq & (RING - 1);
-                it_leaf[j] = leaf;
-                it_w[j] = weight;
-                it_own[j] = (uint8_t)lane;
-                qpos = __builtin_amdgcn_alignbit(seq, qpos, 8u);  // (qpos >> 8) | seq << 24
-                qsh -= 8u;
-            }
-            ring_tail += (uint32_t)__builtin_popcountll(m_push);
-        }
-        TL_ADD(tl_march);
-
-        // ================= (C') retire the finished rays, start the new ones =================
-        if (refill) {
-            if (done) {
-                ray.stopped = stopped;
+            if (done)
                 finish_ray<FMA, COUNT>(
                     p, ray, rc,
                     reinterpret_cast<uint8_t*>(((uint64_t)px_hi << 32) | (uint64_t)px_lo), fin_xy,
                     (int)fin_frame);
-            }
             if (vacant) {
-                if (!take) {  // no ray: not alive
+                ray.active = ray.entered = take;
+                if (!take) {  // (no ray: not alive)
                     ray.t = 0.f;
                     ray.tmax = -1.f;
-                    ray_id = kNoRay;
                 }
                 ray.out[0] = ray.out[1] = ray.out[2] = ray.out[3] = 0.f;
                 ray.light = 1.f;
@@ -1636,117 +1420,130 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 qsh = 32u;
                 qpos = 0;
             }
-            TL_ADD(tl_refill);
-            if (exhausted && !wave_any(ray_id != kNoRay)) break;  // (nothing queued either: every lane was vacant)
+        }
+        if (!wave_any(ray.active)) {
+            if (exhausted) break;
+            continue;
         }
 
-        // ================= (B') colour of the round's items =================
-        // Every lane takes ONE item -- whoever owns it; afterwards every owner adds the
-        // contributions of its own items, oldest first (= the reference's accumulation order,
-        // rt_core.cuh:161).
-        if (n_sh > 0) {
-            TL3_SHADE(n_sh);
-            const uint32_t jmine = (sh_head + (uint32_t)lane) & (RING - 1);
-            if (!EARLY_FREE) {
-                sh_weight = have_item ? it_w[jmine] : 0.f;
-                if (HAS_BASIS && have_item) sh_own4 = (int)it_own[jmine] << 2;
+        // ---- march: lanes with a live ray and room for another outstanding item ----
+        TL_ADD(tl_refill);
+        // Guard against rays that never end (not in the reference, which would spin): when the
+        // wave has marched kMaxIter rounds without retiring a single ray, whatever is still
+        // marching is cut and reported.  Wave-uniform and checked once per pass through here
+        // (<= march_max rounds), so that a march round carries nothing of it (five vector and
+        // four scalar instructions per round until round 3; -2 % frame time, profiles/r04_*).
+        if (rounds - progress_round >= (uint32_t)kMaxIter) {
+            if (ray.t < ray.tmax) {
+                ray.t = ray.tmax;
+                if (p.status) atomicOr(p.status, 1u);
             }
-            // basis_fn[i] of the ray that owns my item, out of its lane's registers through the LDS
-            // crossbar (every lane executes the permute: a bpermute only reads active lanes)
-            auto basis_of = [&](int i) -> float {
-                return u2f((uint32_t)__builtin_amdgcn_ds_bpermute(sh_own4, (int)f2u(mybasis[i])));
-            };
-            // One-pass flavours fetch each group of basis values right where the (whole) wave uses
-            // it; the two-pass flavour (SH25) computes with half the wave at a time, so it gathers
-            // everything up front while every owner lane is still active.
-            float bfull[ST::kPasses > 1 ? NB : 1];
-            if constexpr (ST::kPasses > 1) {
-#pragma unroll
-                for (int i = 0; i < NB; ++i) bfull[i] = basis_of(i);
-            }
-            auto basis_get = [&](int i) -> float {
-                if constexpr (ST::kPasses > 1) return bfull[i];
-                else return basis_of(i);
-            };
-            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-            if constexpr (ST::kEnabled) {
-#pragma unroll
-                for (int pass = 0; pass < ST::kPasses; ++pass) {
-                    if (pass * ST::kPass < n_sh) {  // wave-uniform
-                        if (pass > 0) {  // (the first pass was requested before the round's wait)
-                            if (p.records_nt)
-                                issue_records<BASIS, true, RING>(p, stage, it_leaf, sh_head, lane, n_sh, pass);
-                            else
-                                issue_records<BASIS, false, RING>(p, stage, it_leaf, sh_head, lane, n_sh, pass);
-                            __syncthreads();  // the DMAs have landed (vmcnt(0)) and are visible
-                            TL_ADD(tl_shade_load);
-                        }
-                        // (one pass: ALL lanes run the arithmetic -- an owner lane without an item
-                        // of its own must stay active for the permutes; only item lanes keep results)
-                        if (ST::kPasses == 1 || lane / ST::kPass == pass) {
-                            const char* row = stage + (lane % ST::kPass) * ST::kRow;
-                            float acc[3];
-                            channel_sums<FMA, BASIS, (VR_SHADE_SCHED_BARRIER != 0) || (BASIS == 25 && VR_SH25_WAVES >= 5)>(row, basis_get, acc);
-                            // rt_core.cuh:161: weight / (1 + expf(-tmp)) per channel
-                            if constexpr (VR_PACKED_EXP) {
-                                const float2v e01 = vr_expf2((float2v){-acc[0], -acc[1]}) + splat2(1.f);
-                                r0 = sh_weight / e01.x;
-                                r1 = sh_weight / e01.y;
-                            } else {
-                                r0 = sh_weight / (1.f + vr_expf(-acc[0]));
-                                r1 = sh_weight / (1.f + vr_expf(-acc[1]));
-                            }
-                            r2 = sh_weight / (1.f + vr_expf(-acc[2]));
-                        }
-                        if (ST::kPasses > 1) __syncthreads();  // rows are free for the next pass
-                        TL_ADD(tl_shade_math);
-                    }
-                }
-            } else {
-                const float b0 = HAS_BASIS ? basis_of(0) : 0.f;  // (every lane: see above)
-                if (have_item) {
-                    if (HAS_BASIS) {  // runtime basis size: first coefficient of each channel only
-                        r0 = sh_weight / (1.f + vr_expf(-(b0 * rec.at(0))));
-                        r1 = sh_weight / (1.f + vr_expf(-(b0 * rec.at(1))));
-                        r2 = sh_weight / (1.f + vr_expf(-(b0 * rec.at(2))));
-                    } else {  // RGBA: out[c] = madd(colour, weight, out[c]) is formed by the owner
-                        r0 = rec.at(0);
-                        r1 = rec.at(1);
-                        r2 = rec.at(2);
-                    }
-                }
-            }
-            __syncthreads();  // every row has been read: `res` may overwrite them
-            if (have_item) {
-                res[0 * kWave + lane] = r0;
-                res[1 * kWave + lane] = r1;
-                res[2 * kWave + lane] = r2;
-                if (!HAS_BASIS) res[3 * kWave + lane] = sh_weight;
-            }
-            __syncthreads();  // contributions are visible
-            TL_ADD(tl_shade_math);
-            const uint32_t head8 = sh_head & 0xFFu;
-#pragma unroll
-            for (int d = 0; d < kOwnerQ; ++d) {
-                const uint32_t qp = __builtin_amdgcn_ubfe(qpos, qsh, 8u);  // my oldest item
-                const uint32_t idx = (qp - head8) & 0xFFu;                // its index within the round
-                if (qsh < 32u && idx < (uint32_t)n_sh) {
-                    if (HAS_BASIS) {
-                        ray.out[0] += res[0 * kWave + idx];
-                        ray.out[1] += res[1 * kWave + idx];
-                        ray.out[2] += res[2 * kWave + idx];
-                    } else {
-                        const float w = res[3 * kWave + idx];
-                        ray.out[0] = P::madd(res[0 * kWave + idx], w, ray.out[0]);
-                        ray.out[1] = P::madd(res[1 * kWave + idx], w, ray.out[1]);
-                        ray.out[2] = P::madd(res[2 * kWave + idx], w, ray.out[2]);
-                    }
-                    qsh += 8u;
-                }
-            }
-            if (!EARLY_FREE) ring_head += (uint32_t)n_sh;
-            TL_ADD(tl_shade_acc);
+            progress_round = rounds;
         }
+        int m = 0;
+        for (; m < p.march_max; ++m) {
+            // (the wave's "anybody marching?" mask comes straight from the two compares: the
+            // ballot of a combined boolean costs two more vector instructions)
+            const unsigned long long m_go = __builtin_amdgcn_ballot_w64(ray.t < ray.tmax) &
+                                            __builtin_amdgcn_ballot_w64(qsh != 0u);
+            if (m_go == 0ull) break;
+            const bool go = ray.t < ray.tmax && qsh != 0u;
+            if (COUNT) {
+                st_march_r++;
+                st_march_l += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(go));
+            }
+            TL3_ROUND(go);
+            bool push = false;
+            uint32_t leaf = 0;
+            float weight = 0.f;
+            if (go) {
+                float pos[3];
+                pos[0] = P::madd(ray.t, ray.dir[0], ray.cen[0]);
+                pos[1] = P::madd(ray.t, ray.dir[1], ray.cen[1]);
+                pos[2] = P::madd(ray.t, ray.dir[2], ray.cen[2]);
+                float cube_sz = 0.f;
+                int levels;
+                uint32_t word;
+                if (N2) {
+                    leaf = query_n2<COUNT>(p, pos, &levels, &word, cur);
+                } else {
+                    leaf = (uint32_t)query_generic<FMA, COUNT>(p, pos, &cube_sz, &levels, &word);
+                }
+                if (COUNT) {
+                    rc.samples++;
+                    rc.child_reads += (uint32_t)levels;
+                }
+                // rt_core.cuh:116: dda / cube_sz
+                const float dda = dda_unit<FMA>(pos, ray.invdir);
+                // N2: cube_sz = 2^levels; x / 2^k == ldexp(x, -k), the same real number rounded once
+                const float t_subcube =
+                    N2 ? __builtin_amdgcn_ldexpf(dda, -levels) : dda / cube_sz;
+                const float delta_t = t_subcube + p.step_size;
+                const float sigma = h2f((uint16_t)(word & 0xFFFFu));
+                bool stop = false;
+                if (sigma > p.sigma_thresh) {
+                    // rt_core.cuh:118-121,174: attenuation, weight and the light update are
+                    // taken now; the colour of this sample -- which nothing else depends on --
+                    // becomes a work item for the shade phase.
+                    if (COUNT) rc.hits++;
+                    const float att = vr_expf(-delta_t * ray.delta_scale * sigma);
+                    weight = ray.light * (1.f - att);
+                    if (COUNT && p.render_depth)  // (depth launches take the FULL flavour)
+                        ray.out[0] = P::madd(weight, ray.t, ray.out[0]);
+                    else if (VR_EXP_FUSED_COLOUR)
+                        push = true;
+                    else
+                        ray.out[1] += weight;
+                    ray.light *= att;
+                    stop = ray.light < p.stop_thresh;
+                }
+                if (stop) {
+                    ray.tmax = -1.f;  // stopped (and no longer alive)
+                    if (COUNT) rc.early++;
+                } else {
+                    ray.t += delta_t;
+                }
+            }
+            // append this step's items to the ring: k-th pushing lane -> tail + k
+            const unsigned long long m_push = __builtin_amdgcn_ballot_w64(push);
+            if (m_push != 0ull) {
+                if (push) {
+                    const uint32_t seq =
+                        ring_tail + __builtin_amdgcn_mbcnt_hi(
+                                        (uint32_t)(m_push >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m_push, 0u));
+                    const uint32_t j = seq & (kRing - 1);
+                    it_leaf[j] = leaf;
+                    it_w[j] = weight;
+                    it_own[j] = (uint8_t)lane;
+                    qpos = __builtin_amdgcn_alignbit(seq, qpos, 8u);  // (qpos >> 8) | seq << 24
+                    qsh -= 8u;
+                }
+                ring_tail += (uint32_t)__builtin_popcountll(m_push);
+                // (a loop: with rounds of fewer than 64 items -- VR_SH16_ROWS < 64 -- one round per
+                // march step would let the ring overflow)
+                while (ring_tail - ring_head >= (uint32_t)ST::kShade) shade_chunk(ST::kShade);
+            }
+            // Lanes whose ray has ended but still has colour items queued can neither march nor
+            // be refilled: once flush_wait of them idle, a partial shade round frees them (the
+            // round costs what a full one costs, so the threshold is a trade: measured below).
+            if (p.flush_wait > 0) {
+                const unsigned long long m_wait =
+                    __builtin_amdgcn_ballot_w64(ray.active && !(ray.t < ray.tmax) && qsh < 32u);
+                if (__builtin_popcountll(m_wait) >= p.flush_wait && ring_tail != ring_head) {
+                    const uint32_t waiting = ring_tail - ring_head;
+                    shade_chunk(waiting < (uint32_t)ST::kShade ? (int)waiting : ST::kShade);
+                }
+            }
+        }
+        rounds += (uint32_t)m;
+        // nobody can march any more (queues full / rays ended): flush what is queued
+        // (at most kShade - 1 + 64 items wait here: two rounds at most)
+        while (ring_tail != ring_head && !wave_any(ray.t < ray.tmax && qsh > 0u)) {
+            const uint32_t waiting = ring_tail - ring_head;
+            shade_chunk(waiting < (uint32_t)ST::kShade ? (int)waiting : ST::kShade);
+        }
+        TL_ADD(tl_march);
     }
     TL_DUMP_FUSED();
     TL3_END();
