@@ -9,7 +9,7 @@ ROCM ?= /opt/rocm
 PKG = volrend_amd
 HOST = $(PKG)/csrc/host
 HOST_SRC = $(HOST)/npz.cpp $(HOST)/n3tree.cpp $(HOST)/camera.cpp $(HOST)/opts.cpp \
-           $(HOST)/imwrite.cpp $(HOST)/renderer.cpp $(HOST)/tile_shard.cpp
+           $(HOST)/imwrite.cpp $(HOST)/renderer.cpp $(HOST)/tile_shard.cpp $(HOST)/volume_renderer.cpp
 HOST_OBJ = $(HOST_SRC:.cpp=.o)
 CXXFLAGS = -O2 -std=c++17 -fPIC -Wall -Wextra -Iinclude
 
@@ -18,11 +18,19 @@ all: lib host cli
 lib:
 	python3 -m volrend_amd.build
 
-$(HOST)/%.o: $(HOST)/%.cpp
+# every object depends on every kept header: a layout change (RenderOptions, N3Tree) must never
+# leave a stale object in the archive
+HOST_HDR = $(wildcard include/*.h include/volrend/*.hpp include/volrend/internal/*.hpp)
+
+$(HOST)/%.o: $(HOST)/%.cpp $(HOST_HDR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
 # the multi-GPU tile shard talks to the HIP runtime and RCCL directly
-$(HOST)/tile_shard.o: $(HOST)/tile_shard.cpp include/volrend/internal/tile_shard.hpp
+$(HOST)/tile_shard.o: $(HOST)/tile_shard.cpp $(HOST_HDR)
+	$(CXX) $(CXXFLAGS) -I$(ROCM)/include -D__HIP_PLATFORM_AMD__ -c $< -o $@
+
+# ... and so does the renderer facade (its frames are device memory)
+$(HOST)/volume_renderer.o: $(HOST)/volume_renderer.cpp $(HOST_HDR)
 	$(CXX) $(CXXFLAGS) -I$(ROCM)/include -D__HIP_PLATFORM_AMD__ -c $< -o $@
 
 host: $(PKG)/libvolrend_host.a
@@ -30,7 +38,7 @@ $(PKG)/libvolrend_host.a: $(HOST_OBJ)
 	ar rcs $@ $(HOST_OBJ)
 
 cli: $(PKG)/bin/volrend_headless
-$(PKG)/bin/volrend_headless: $(HOST)/main_headless.cpp $(PKG)/libvolrend_host.a lib
+$(PKG)/bin/volrend_headless: $(HOST)/main_headless.cpp $(PKG)/libvolrend_host.a $(HOST_HDR) lib
 	mkdir -p $(PKG)/bin
 	$(CXX) -O2 -std=c++17 -Iinclude -I$(ROCM)/include -D__HIP_PLATFORM_AMD__ \
 	  $(HOST)/main_headless.cpp $(PKG)/libvolrend_host.a -L$(PKG) -lvolrend_hip \

@@ -150,11 +150,15 @@ def committed_traffic(config: str, fp: str, profiles_dir: str | None = None, hav
         found.append((tj, rel))
     found.sort(key=lambda x: 0 if want_fpl is not None and int(x[0]["frames_per_launch"]) == want_fpl else 1)
     for tj, rel in found[:1]:
+        committed_traffic.last_profile = tj  # (the same file's instruction counts: see main)
         return (tj["read_bytes_per_frame"] + tj.get("write_bytes_per_frame", 0.0),
                 f"{rel}: rocprofv3 --pmc passes at {tj['frames_per_launch']} frames per launch, "
                 f"TCC_EA0_RDREQ_128B*128 + _64B*64 + _32B*32 + WRITE_SIZE, kernel source hash verified",
                 int(tj["frames_per_launch"]))
     return None, reason, None
+
+
+committed_traffic.last_profile = None
 
 
 def parity_check(stree, checks, width, height, focal, fp):
@@ -231,6 +235,14 @@ def main():
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the post-run comparison of timed frames with the CPU oracle")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--preroll", type=int, default=128,
+                    help="untimed frames rendered directly in front of the W warm-up steps, so that the "
+                         "timed region finds the GPU in the power state of a running render loop "
+                         "(after ~5 ms of idling an MI355X needs ~30 ms of work to be back at full "
+                         "clocks: profiles/r04_lone_launch_probe.jsonl); 0 = none")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="after the timed region, the identical K-step region is run this many more "
+                         "times (not part of value / ms_per_step): the line's own noise floor")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: everything else that writes to fd 1 (RCCL prints
@@ -427,6 +439,8 @@ def main():
             unique_launch = (n, tree.touch_count(reset=True))
         jd += n
     tree.touch_count(reset=True)
+    torch.cuda.synchronize()
+    sched = tree.sched_stats()  # of the launches above only: the timed region's poses and batching
     unique_frames = []
     side = torch.zeros((1, 7), dtype=torch.int64, device=dev)
     for i in range(4):  # four single frames spread over the timed poses
@@ -439,7 +453,7 @@ def main():
     torch.cuda.synchronize()
     cnt = dict(zip(_abi.COUNTER_FIELDS, [int(v) for v in counters.sum(dim=0).cpu().tolist()]))
     alg_bytes_per_frame = cnt["alg_bytes"] / n_distinct  # this rank's share of a frame
-    sched = tree.sched_stats()
+    tree.sched_stats()  # (drop the four single-frame launches)
     log(f"[bench r{rank}] sched per frame: " + ", ".join(
         f"{k}={v / n_distinct:.0f}" for k, v in sched.items()) +
         f"; march util {sched['march_lanes'] / max(64 * sched['march_rounds'], 1):.2f}"
@@ -454,6 +468,13 @@ def main():
     # ---- W untimed warm-up steps, directly in front of the timed ones (everything that is
     # neither warm-up nor timed -- counters, B_unique -- has run before: the chip enters the timed
     # region the way a render loop in progress would find it)
+    # Power state: the host-side work above (counters, marshalling) leaves the GPU idle for tens of
+    # milliseconds, and an MI355X that has idled for >= 5 ms runs its next ~30 ms of work at reduced
+    # clocks -- a lone 20-frame launch takes 5.55 ms instead of 5.04 (tools/lone_launch_probe.py).
+    # A render loop in progress never sees that state, so the warm-up is preceded by `preroll`
+    # untimed frames of other poses, enqueued back to back with it (disclosed in config.preroll).
+    if args.preroll > 0:
+        run(args.preroll, 100)
     if args.warmup > 0:
         run(args.warmup, 0)
     barrier()
@@ -474,6 +495,23 @@ def main():
         for i in sorted({0, n_last - 1}):
             parity_frames.append((first_last + i, pose_of(first_last + i),
                                   frame_sets[j_last % 2][i].cpu().numpy()))
+
+    # ---- the line's own noise floor: the identical K-step region, R more times (same poses, same
+    # prepared launches, same barriers; none of it enters value / ms_per_step) ----
+    repeat_ms = []
+    for _ in range(max(args.repeats, 0)):
+        barrier()
+        torch.cuda.synchronize()
+        t_rep = time.perf_counter()
+        run(K, args.warmup)
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t_rep
+        if use_dist:
+            tr_ = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else dev)
+            dist.all_reduce(tr_, op=dist.ReduceOp.MAX)
+            dt = float(tr_.item())
+        repeat_ms.append(dt / K * 1e3)
 
     if os.environ.get("VR_TIMELINE"):  # profiling build (-DVR_TIMELINE=1): per-phase cycle sums
         tl = tree.sched_stats()
@@ -526,11 +564,7 @@ def main():
                                 f"run launched {launch_sizes[0]} -- bytes per frame scaled to the "
                                 f"launch size, not measured at it")
 
-    tune_kv = dict(kv.split("=") for kv in args.tune.split(",")) if args.tune else {}
-    split = int(tune_kv["split"]) if "split" in tune_kv else int(os.environ.get("VR_SPLIT", "-1"))
-    if split < 0:  # the library's default (vr_api.cpp): split kernel for one-frame launches only
-        split = int(min(B, K) == 1 and cfg["basis_dim"] != 25)
-    kernel_name = "render_ms_kernel" if split else "render_kernel"
+    kernel_name = "render_kernel"
     if rank == 0:
         # replicas: every rank rendered its own K frames; tile mode: the K frames were shared
         rays_total = W * H * K * (world if replicas else 1)
@@ -561,6 +595,9 @@ def main():
                 "launches": n_launch,
                 "pcie_inclusive": bool(args.readback),
                 "launch_streams": n_streams,
+                "preroll": (f"{args.preroll} untimed frames of other poses directly in front of the "
+                            f"{args.warmup} warm-up steps (GPU clocks of a running render loop; "
+                            f"--preroll 0 = a launch out of an idle GPU)") if args.preroll > 0 else 0,
                 "sharded_frame_matches_single_gpu": shard_ok,
                 "parallelism": "single GPU" if world == 1 else (
                     f"{world} replicas: one tree (seeds 1010..) and pose stream per GPU, no "
@@ -600,6 +637,27 @@ def main():
                 "unique_lines_per_frame_by_array": {
                     k: int(np.mean([u[k] for u in unique_frames])) for k in unique_frames[0]},
             },
+        }
+        if repeat_ms:
+            allms = sorted([elapsed / K * 1e3] + repeat_ms)
+            result["repeats"] = {
+                "what": "the identical K-step region repeated after the timed one (same launches, "
+                        "same poses); min / median / max include the timed region itself",
+                "ms_per_step": [round(x, 5) for x in repeat_ms],
+                "min": round(allms[0], 5), "median": round(allms[len(allms) // 2], 5),
+                "max": round(allms[-1], 5)}
+        # lane utilisation of the march and shade rounds (instrumented flavour, same poses, outside
+        # the timed region) and -- from the committed PMC passes of these very sources -- the
+        # instructions a frame executes: a later change is checkable against this line alone
+        prof = committed_traffic.last_profile or {}
+        result["sched"] = {
+            "march_util": round(sched["march_lanes"] / max(64 * sched["march_rounds"], 1), 4),
+            "shade_util": round(sched["shade_lanes"] / max(64 * sched["shade_rounds"], 1), 4),
+            "march_rounds_per_frame": int(sched["march_rounds"] / n_distinct),
+            "shade_rounds_per_frame": int(sched["shade_rounds"] / n_distinct),
+            "valu_insts_per_frame": prof.get("valu_insts_per_frame"),
+            "salu_insts_per_frame": prof.get("salu_insts_per_frame"),
+            "valu_source": traffic_src if prof else "no hash-verified PMC profile of these sources",
         }
         if parity_frames:
             result["parity"] = parity_check(stree, parity_frames, W, H, focal, args.fp)

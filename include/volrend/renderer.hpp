@@ -1,0 +1,75 @@
+// volrend::VolumeRenderer -- the reference's renderer facade (include/volrend/renderer.hpp:11-42,
+// src/cuda_renderer.cpp:83-195) without OpenGL: the frame is a linear RGBA8 buffer in device
+// memory instead of a GL renderbuffer shared through CUDA-GL interop.
+//
+//   VolumeRenderer r;            // the reference needs a current GL context here; this does not
+//   r.resize(800, 800);
+//   r.set(tree);                 // narrows options.basis_minmax to the tree's basis, as upstream
+//   r.camera.center = ...;  r.options.step_size = ...;
+//   r.render();                  // camera._update() + clear + launch_renderer (interactive path:
+//                                // offscreen = false, i.e. composited over what is in the frame)
+//   r.read_frame(host_rgba8);    // or frame(): the device pointer, valid until the next-but-one render()
+//
+// What upstream draws with GL BEFORE the ray march -- meshes, the probe cube, the octree grid --
+// reaches the kernel as two images: the RGBA8 colour it composites over and an R32F depth that
+// ends each ray (cuda_renderer.cpp:83-126; volrend.cu:142-147,152-165).  Here a caller that has
+// such images hands them in as device buffers (set_underlay); without them the frame is cleared to
+// background_brightness and the depth to 1e9 exactly as upstream's glClear calls do
+// (cuda_renderer.cpp:85-92).  `meshes` is not offered: rasterising them is GL work (north_star:
+// no GL fallback).
+#pragma once
+#include <cstdint>
+#include <memory>
+
+#include "volrend/camera.hpp"
+#include "volrend/n3tree.hpp"
+#include "volrend/render_options.hpp"
+
+namespace volrend {
+
+struct VolumeRenderer {
+    explicit VolumeRenderer();
+    ~VolumeRenderer();
+    VolumeRenderer(const VolumeRenderer&) = delete;
+    VolumeRenderer& operator=(const VolumeRenderer&) = delete;
+
+    // Render the currently set tree (asynchronous, like upstream: the frame is complete once
+    // stream() is idle; read_frame() waits)
+    void render();
+
+    // Set volumetric data to render (must be uploaded: N3Tree::open does that)
+    void set(N3Tree& tree);
+
+    // Clear the volumetric data
+    void clear();
+
+    // Resize the buffer
+    void resize(int width, int height);
+
+    // Name identifying the renderer backend
+    const char* get_backend();
+
+    // Camera instance
+    Camera camera;
+
+    // Rendering options
+    RenderOptions options;
+
+    // ---- in place of the GL framebuffer ----
+    // Device images every render() starts from (both optional, camera.width x camera.height,
+    // dense rows): what upstream's meshes leave in the colour and the R32F depth attachment.
+    // The buffers stay the caller's; they are copied on render()'s stream.
+    void set_underlay(const void* rgba8_dev, const float* depth_dev);
+    // The frame the last render() wrote (device memory, RGBA8, width * 4 bytes per row)
+    const uint8_t* frame() const;
+    // Waits for the last render() and copies its frame to host memory (width * height * 4 bytes)
+    void read_frame(void* host_rgba8);
+    // The stream render() enqueues on (hipStream_t)
+    void* stream() const;
+
+   private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+}  // namespace volrend

@@ -243,13 +243,11 @@ int vr_reserve(vr_tree_t tree, int width, int height, int n_frames);
 int vr_reserve_tiles(vr_tree_t tree, int width, int height, int n_frames, int tile_w, int tile_h,
                      int world, int n_slots);
 /* Sticky device status word of the tree's launches: bit 0 = some ray hit the 2^22-sample
- * guard (the reference would still be looping); bit 1 = a march wave of the split kernel gave
- * up waiting for its shade wave (a bounded wait, never expected to trip: the launch's pixels are
- * incomplete if it does).  Synchronous; reset != 0 clears it.
+ * guard (the reference would still be looping).  Synchronous; reset != 0 clears it.
  * vr_render* refuses step_size <= 0 / NaN (VR_ERR_INVALID_ARGUMENT), where the reference
  * hangs, so the bit only ever fires on pathological step_size / scene combinations. */
 int vr_tree_status(vr_tree_t tree, uint32_t* status, int reset);
-/* Scheduling / layout knobs ("march_max", "refill_min", "waves_per_cu", "split", "records_nt",
+/* Scheduling / layout knobs ("march_max", "refill_min", "waves_per_cu", "records_nt",
  * "top_levels", "brick_levels", ...); results never depend on them.  Every tree carries its own
  * copy, taken at upload (or from the source of a clone) from the process defaults:
  *   vr_set_tuning       changes the DEFAULTS of trees uploaded afterwards (serialised);

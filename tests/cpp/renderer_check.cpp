@@ -1,0 +1,90 @@
+// renderer_check -- volrend::VolumeRenderer (reference include/volrend/renderer.hpp:11-42,
+// src/cuda_renderer.cpp:83-195) on a real GPU, without OpenGL.  Driven by
+// tests/test_gpu_renderer.py, which renders the same thing with the CPU oracle's
+// compositing path (offscreen = 0).
+//
+//   renderer_check <tree.npz> <spec.txt> <out.raw>
+// spec: "size W H FX FY", "background_brightness b", "underlay <rgba.raw> <depth.raw>" (optional),
+//       one "cam cx cy cz bx by bz" per frame (camera centre and v_back; v_world_up stays +z).
+// stdout: one "transform f0 .. f11" line per frame (what Camera::_update made of the vectors)
+//         and "basis_minmax a b backend NAME".
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "volrend/renderer.hpp"
+
+static std::vector<char> slurp(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+int main(int argc, char* argv[]) {
+    using namespace volrend;
+    if (argc < 4) return 2;
+    try {
+        N3Tree tree(argv[1]);
+        VolumeRenderer r;
+        if (r.frame() != nullptr) return 6;  // nothing rendered yet
+        std::ifstream spec(argv[2]);
+        int w = 0, h = 0;
+        std::string under_rgba, under_depth;
+        std::vector<std::vector<float>> cams;
+        for (std::string line; std::getline(spec, line);) {
+            std::istringstream is(line);
+            std::string key;
+            if (!(is >> key)) continue;
+            if (key == "size") is >> w >> h >> r.camera.fx >> r.camera.fy;
+            else if (key == "background_brightness") is >> r.options.background_brightness;
+            else if (key == "underlay") is >> under_rgba >> under_depth;
+            else if (key == "cam") {
+                std::vector<float> c(6);
+                for (float& v : c) is >> v;
+                cams.push_back(c);
+            } else return 2;
+        }
+        r.resize(w, h);
+        if (r.camera.width != w || r.camera.height != h) return 7;
+        r.options.basis_minmax[1] = 24;
+        r.set(tree);  // must narrow basis_minmax to the tree's basis (cuda_renderer.cpp:176-177)
+        void *d_rgba = nullptr, *d_depth = nullptr;
+        if (!under_rgba.empty()) {
+            const std::vector<char> a = slurp(under_rgba), b = slurp(under_depth);
+            if (a.size() != (size_t)w * h * 4 || b.size() != (size_t)w * h * 4) return 8;
+            if (hipMalloc(&d_rgba, a.size()) != hipSuccess || hipMalloc(&d_depth, b.size()) != hipSuccess) return 4;
+            if (hipMemcpy(d_rgba, a.data(), a.size(), hipMemcpyHostToDevice) != hipSuccess) return 4;
+            if (hipMemcpy(d_depth, b.data(), b.size(), hipMemcpyHostToDevice) != hipSuccess) return 4;
+            r.set_underlay(d_rgba, (const float*)d_depth);
+        }
+        std::vector<uint8_t> host((size_t)w * h * 4 * (cams.size() + 1));
+        for (size_t i = 0; i < cams.size(); ++i) {
+            r.camera.center = glm::vec3(cams[i][0], cams[i][1], cams[i][2]);
+            r.camera.v_back = glm::vec3(cams[i][3], cams[i][4], cams[i][5]);
+            r.render();
+            r.read_frame(host.data() + (size_t)w * h * 4 * i);
+            const float* t = glm::value_ptr(r.camera.transform);
+            printf("transform");
+            for (int k = 0; k < 12; ++k) printf(" %.9g", t[k]);
+            printf("\n");
+        }
+        // without a tree render() leaves the cleared frame / the underlay (cuda_renderer.cpp:114)
+        r.clear();
+        r.render();
+        r.read_frame(host.data() + (size_t)w * h * 4 * cams.size());
+        FILE* fp = fopen(argv[3], "wb");
+        if (!fp || fwrite(host.data(), 1, host.size(), fp) != host.size()) return 5;
+        fclose(fp);
+        printf("basis_minmax %d %d backend %s\n", r.options.basis_minmax[0], r.options.basis_minmax[1],
+               r.get_backend());
+        if (d_rgba) (void)hipFree(d_rgba);
+        if (d_depth) (void)hipFree(d_depth);
+    } catch (const std::exception& e) {
+        printf("EXCEPTION %s\n", e.what());
+        return 3;
+    }
+    return 0;
+}

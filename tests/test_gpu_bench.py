@@ -38,6 +38,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     par = d["parity"]
     assert par["frames_checked"] >= 1 and par["rgba8_equal"] is True and par["psnr_db"] == "inf"
     assert par["max_abs_diff_rgb8"] == 0
+    # the line's own noise floor and the scheduler's lane utilisation travel with it
+    rep = d["repeats"]
+    assert len(rep["ms_per_step"]) == 5 and rep["min"] <= rep["median"] <= rep["max"]
+    assert 0 < d["sched"]["march_util"] <= 1 and 0 < d["sched"]["shade_util"] <= 1
+    assert "untimed frames" in d["config"]["preroll"]
     roof = d["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3)

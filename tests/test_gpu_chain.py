@@ -2,8 +2,7 @@
 own render_kernel / trace_ray compiled for the host (oracle/_ref/libvolrend_ref.so, which travels
 to the GPU box with the snapshot).  tests/test_oracle_vs_ref.py pins oracle == reference on the
 CPU; this file repeats that comparison next to the kernel's output so that the GPU test record
-alone shows kernel == oracle == reference, for both kernel organisations of the FAST flavours
-(fused march/shade waves, and march / shade on separate waves: tuning key ``split``).
+alone shows kernel == oracle == reference.
 """
 import numpy as np
 import pytest
@@ -20,14 +19,6 @@ def torch_cuda():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch
-
-
-@pytest.fixture(params=[0, 1], ids=["fused", "split"])
-def split(request):
-    from volrend_amd import api
-    api.set_tuning(split=request.param)
-    yield request.param
-    api.set_tuning(split=-1)
 
 
 def kernel_frame(torch, tree, tr, w, h, f, fp_mode=0, ndc=None, **opt_kw):
@@ -60,7 +51,7 @@ CASES = [
 
 @pytest.mark.parametrize("fmt,basis_dim,kw", CASES,
                          ids=[f"{c[0]}{c[1]}-{'-'.join(c[2]) or 'default'}" for c in CASES])
-def test_kernel_equals_oracle_equals_reference(torch_cuda, split, fmt, basis_dim, kw):
+def test_kernel_equals_oracle_equals_reference(torch_cuda, fmt, basis_dim, kw):
     if ob.ref_lib() is None:
         pytest.skip("oracle/_ref/libvolrend_ref.so missing (build() where the reference is mounted)")
     tree = common.small_scene(depth=6, basis_dim=basis_dim, fmt=fmt, seed=300 + basis_dim)
@@ -79,7 +70,7 @@ def test_kernel_equals_oracle_equals_reference(torch_cuda, split, fmt, basis_dim
     assert np.array_equal(acc_k.view(np.uint32), acc_r.view(np.uint32)), "kernel != reference (fp32)"
 
 
-def test_ndc_chain(torch_cuda, split):
+def test_ndc_chain(torch_cuda):
     if ob.ref_lib() is None:
         pytest.skip("oracle/_ref/libvolrend_ref.so missing")
     tree = common.small_scene(depth=5, basis_dim=9, seed=351)
@@ -96,7 +87,7 @@ def test_ndc_chain(torch_cuda, split):
 
 
 @pytest.mark.parametrize("fp_mode", [0, 1])
-def test_random_sweep_both_organisations(torch_cuda, split, fp_mode):
+def test_random_sweep(torch_cuda, fp_mode):
     """The seeded random configurations of the CPU pin (formats, odd sizes, cameras inside the
     volume, degenerate thresholds, bbox, basis range, rotation, depth mode, NDC), through both
     kernel organisations and both FP models."""
@@ -112,7 +103,7 @@ def test_random_sweep_both_organisations(torch_cuda, split, fp_mode):
             f"seed {seed} {tag}: accumulators differ"
 
 
-def test_batch_of_poses_both_organisations(torch_cuda, split):
+def test_batch_of_poses(torch_cuda):
     """A bench-shaped launch (several poses, one queue, rays of different frames in one wave;
     enough rays that waves refill many times) frame by frame against the oracle."""
     torch = torch_cuda
@@ -139,7 +130,7 @@ def test_batch_of_poses_both_organisations(torch_cuda, split):
         assert np.array_equal(got_acc[i].view(np.uint32), acc_o.view(np.uint32)), f"pose {i}"
 
 
-def test_tree_with_backward_links(torch_cuda, split):
+def test_tree_with_backward_links(torch_cuda):
     """A valid tree whose node order is scrambled (children at LOWER indices than their parents:
     relative links may be negative in the file format): the upload's index-order sweep gives up
     at the first backward link and the general walk takes over; the picture is the oracle's."""
@@ -168,7 +159,7 @@ def test_tree_with_backward_links(torch_cuda, split):
 
 
 @pytest.mark.parametrize("xcd_queues", [1, 0], ids=["8 queues", "1 queue"])
-def test_every_ray_queue_is_drained(torch_cuda, split, xcd_queues):
+def test_every_ray_queue_is_drained(torch_cuda, xcd_queues):
     """The ray buffer is cut into 8 queues, one per XCD; a wave steals from a foreign queue only
     while that queue holds a good part of its rays and leaves the rest to the queue's own waves
     (vr_kernels.hip, grab_chunk).  A launch of fewer waves than queues has queues WITHOUT waves of

@@ -125,9 +125,9 @@ def test_per_tree_tuning_and_tile_reserve(torch_cuda):
     tree = common.small_scene(depth=6, basis_dim=9, seed=515)
     a = api.N3Tree.from_synth(tree)
     b = api.N3Tree.from_synth(tree)
-    a.set_tuning(split=1, refill_min=8, march_max=4)
-    b.set_tuning(split=0, refill_min=40, waves_per_cu=12)
-    c = a.clone_to(0)  # inherits split=1, refill_min=8, march_max=4
+    a.set_tuning(flush_wait=6, refill_min=8, march_max=4)
+    b.set_tuning(refill_min=40, waves_per_cu=12)
+    c = a.clone_to(0)  # inherits flush_wait=6, refill_min=8, march_max=4
     for bad_key in ("top_levels", "brick_levels", "no_such_knob"):
         with pytest.raises(_abi.VolrendError):
             a.set_tuning(**{bad_key: 3})
@@ -141,7 +141,7 @@ def test_per_tree_tuning_and_tile_reserve(torch_cuda):
         t.reserve(w, h, len(trs), shard=api.TileShard(tw, th, 0, world, compact=True), n_slots=3)
         with pytest.raises(_abi.VolrendError):
             t.reserve(w, h, len(trs), n_slots=9)
-        # whole frames (one launch of 3 poses, then one-frame launches: the split-by-default case)
+        # whole frames (one launch of 3 poses, then a one-frame launch)
         imgs = torch.zeros((len(trs), h, w, 4), dtype=torch.uint8, device="cuda")
         api.launch_renderer_batch(t, cam, trs, api.RenderOptions(), list(imgs), None, True)
         single = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")

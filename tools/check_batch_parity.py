@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """One bench-shaped launch against the oracle: N consecutive poses of a config in ONE
 vr_render_batch launch (the shape bench.py times), every frame compared bit for bit.
-    python tools/check_batch_parity.py [config] [n_frames] [first_pose] [split]   (on the GPU box)
-split: -1 = the library's choice (default), 0 = fused kernel, 1 = march / shade on separate waves."""
+    python tools/check_batch_parity.py [config] [n_frames] [first_pose]   (on the GPU box)"""
 import json
 import os
 import sys
@@ -22,12 +21,10 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "C1"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     first = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-    split = int(sys.argv[4]) if len(sys.argv) > 4 else -1
     cfg = synth.CONFIGS[name]
     stree = bench.load_or_make_tree(synth, name, 0, lambda: None)
     W, H, focal = cfg["width"], cfg["height"], cfg["focal"]
     t = api.N3Tree.from_synth(stree)
-    t.set_tuning(split=split)
     th = ob.TreeHandle(stree)
     poses = synth.make_poses(200)
     trs = [synth.c2w_to_transform(poses[(first + i) % 200]) for i in range(n)]
@@ -42,7 +39,7 @@ def main():
                                want_accum=False)
         if not np.array_equal(got[i], want):
             bad.append(i)
-    print(json.dumps({"config": name, "frames_in_one_launch": n, "first_pose": first, "split": split,
+    print(json.dumps({"config": name, "frames_in_one_launch": n, "first_pose": first,
                       "frames_bit_equal_to_oracle": n - len(bad), "mismatching_frames": bad,
                       "oracle_seconds": round(time.time() - t0, 1), "status": t.status()}))
     t.free_device()

@@ -56,7 +56,7 @@ GROUPS = {
     "sq4": "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_WAIT_INST_LDS",
     # TA_* and TD_* counters abort rocprofv3 on this pool (measured twice in round 1): not offered
 }
-SOURCES = ["volrend_amd/csrc/vr_kernels.hip", "volrend_amd/csrc/vr_device_math.h",
+SOURCES = ["volrend_amd/csrc/vr_kernels.hip", "volrend_amd/csrc/vr_device_math.h", "volrend_amd/csrc/vr_experiment_hooks.h",
            "volrend_amd/csrc/vr_internal.h", "volrend_amd/csrc/vr_api.cpp", "include/volrend_hip.h"]
 
 
@@ -109,20 +109,15 @@ def main():
     ap.add_argument("--keep-csv", default="", help="copy the raw rocprofv3 CSVs here")
     ap.add_argument("--timeout", type=int, default=300)
     ap.add_argument("--bench-args", default="", help="extra bench.py arguments (quoted)")
-    ap.add_argument("--split", type=int, default=-1,
-                    help="kernel organisation: 1 = march / shade on separate waves (render_ms_kernel), "
-                         "0 = fused (render_kernel), -1 = the library's default for the config")
     args = ap.parse_args()
 
     from volrend_amd import synth
     cfg = synth.CONFIGS[args.config]
     basis = cfg["basis_dim"] if cfg["fmt"] != "RGBA" else -1
-    split = args.split if args.split >= 0 else int(args.batch == 1 and basis != 25)  # vr_api.cpp's default
     fpi = 1 if args.fp == "fma" else 0
-    kernel = f"render_ms_kernel<{fpi}, {basis}>" if split else f"render_kernel<{fpi}, {basis}, 0>"
+    kernel = f"render_kernel<{fpi}, {basis}, 0>"
     bench_args = ["--config", args.config, "--fp", args.fp, "--batch", str(args.batch), "--steps",
                   str(2 * args.batch), "--warmup", str(args.batch), "--no-cpu-baseline", "--no-parity",
-                  *(["--tune", f"split={args.split}"] if args.split >= 0 else []),
                   *args.bench_args.split()]
     tmp = tempfile.mkdtemp(prefix="vr_pmc_")
     c, durations, failed = {}, {}, []

@@ -7,7 +7,7 @@ marched all its samples one after the other, so  launch time / longest ray  is a
 the time per dependent round at that load; the 8x8 launch IS one chain.  The per-ray sample counts
 come from the CPU oracle (measurement tooling, like every file under tools/).
 
-    python tools/round_time_probe.py [--config C1] [--sizes 8,16,...] [--tunes "split=0;split=1"]
+    python tools/round_time_probe.py [--config C1] [--sizes 8,16,...] [--tunes ";refill_min=12"]
 """
 from __future__ import annotations
 
@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--config", default="C1")
     ap.add_argument("--sizes", default="8,16,32,64,128,256,400,800")
     ap.add_argument("--poses", default="10,60,110")
-    ap.add_argument("--tunes", default="split=0;split=1")
+    ap.add_argument("--tunes", default="")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--out", default="")
     args = ap.parse_args()

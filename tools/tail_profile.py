@@ -6,7 +6,7 @@ that ended.  From it: how many waves are alive, what they are doing, how long a 
 how full the waves are -- while the ray queue still feeds them and in the tail after it.
 
     python -m volrend_amd.build --variant tl3 -DVR_TIMELINE=3
-    python tools/tail_profile.py [--config C1] [--frames 1] [--tunes "split=0"]
+    python tools/tail_profile.py [--config C1] [--frames 1] [--tunes ""]
 """
 from __future__ import annotations
 
@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--variant", default="tl3")
     ap.add_argument("--frames", default="1")
     ap.add_argument("--first-pose", type=int, default=5)
-    ap.add_argument("--tunes", default="split=0")
+    ap.add_argument("--tunes", default="")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
 

@@ -28,6 +28,8 @@ def run_cli(npz, pose, *flags, reps=3):
     runs = [_run_cli_once(npz, pose, *flags) for _ in range(reps)]
     best = min(runs, key=lambda r: r["upload_ms"])
     best = dict(best, all_upload_ms=[r["upload_ms"] for r in runs])
+    if any("phases" in r for r in runs):
+        best["all_phases"] = [r.get("phases") for r in runs]
     return best
 
 
@@ -40,8 +42,13 @@ def _run_cli_once(npz, pose, *flags):
         raise RuntimeError(r.stderr[-2000:])
     m = re.search(r"INFO: tree ready: npz load[^0-9]* ([0-9.]+) ms, device upload[^0-9]* ([0-9.]+) ms",
                   r.stderr)
-    return {"npz_load_ms": float(m.group(1)), "upload_ms": float(m.group(2)),
-            "process_wall_s": round(wall, 2)}
+    out = {"npz_load_ms": float(m.group(1)), "upload_ms": float(m.group(2)),
+           "process_wall_s": round(wall, 2)}
+    # VR_UPLOAD_TIMING=1: the phases of vr_tree_upload as the library reports them
+    phases = [l[len("[volrend_hip] "):] for l in r.stderr.splitlines() if l.startswith("[volrend_hip] ")]
+    if phases:
+        out["phases"] = phases
+    return out
 
 
 def main():

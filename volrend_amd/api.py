@@ -345,7 +345,7 @@ class N3Tree:
 
     def set_tuning(self, **kw) -> None:
         """Scheduling knobs of THIS tree (vr_tree_set_tuning): march_max, refill_min,
-        waves_per_cu, split, records_nt, ...  Results never depend on them."""
+        waves_per_cu, records_nt, ...  Results never depend on them."""
         for k, v in kw.items():
             _abi.check(_abi.lib().vr_tree_set_tuning(self.handle, k.encode(), int(v)))
 

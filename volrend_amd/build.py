@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvolrend_hip.so")
 SOURCES = ["vr_kernels.hip", "vr_api.cpp"]
-HEADERS = ["vr_internal.h", "vr_device_math.h", os.path.join(ROOT, "include", "volrend_hip.h")]
+HEADERS = ["vr_internal.h", "vr_device_math.h", "vr_experiment_hooks.h", os.path.join(ROOT, "include", "volrend_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

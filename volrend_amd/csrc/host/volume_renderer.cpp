@@ -1,0 +1,147 @@
+// volume_renderer.cpp -- volrend::VolumeRenderer over a linear device frame (no OpenGL);
+// see include/volrend/renderer.hpp.  Follows src/cuda_renderer.cpp:83-195 step for step.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <stdexcept>
+#include <string>
+
+#include "volrend/renderer.hpp"
+#include "volrend/renderer_kernel.hpp"
+
+namespace volrend {
+namespace {
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess)
+        throw std::runtime_error(std::string("VolumeRenderer: ") + what + ": " + hipGetErrorString(e));
+}
+}  // namespace
+
+struct VolumeRenderer::Impl {
+    const N3Tree* tree = nullptr;
+    hipStream_t stream = nullptr;
+    // two frames, as upstream's two framebuffers (cuda_renderer.cpp:210-214): render() writes
+    // one while the consumer may still read the other
+    uint8_t* rgba[2] = {nullptr, nullptr};
+    float* depth[2] = {nullptr, nullptr};
+    int buf_index = 0, last = -1;
+    int width = 0, height = 0;  // size of the allocations
+    const void* under_rgba = nullptr;
+    const float* under_depth = nullptr;
+
+    void start() {  // cuda_renderer.cpp:59-81 without the GL objects
+        if (!stream) hip_check(hipStreamCreate(&stream), "hipStreamCreate");
+    }
+    void release() {
+        for (int i = 0; i < 2; ++i) {
+            if (rgba[i]) (void)hipFree(rgba[i]);
+            if (depth[i]) (void)hipFree(depth[i]);
+            rgba[i] = nullptr;
+            depth[i] = nullptr;
+        }
+        width = height = 0;
+        last = -1;
+    }
+    void allocate(int w, int h) {
+        if (w == width && h == height) return;
+        if (stream) hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        release();
+        if (w <= 0 || h <= 0) return;
+        for (int i = 0; i < 2; ++i) {
+            hip_check(hipMalloc((void**)&rgba[i], (size_t)w * h * 4), "hipMalloc(frame)");
+            hip_check(hipMalloc((void**)&depth[i], (size_t)w * h * 4), "hipMalloc(depth)");
+        }
+        width = w;
+        height = h;
+    }
+    ~Impl() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        release();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+VolumeRenderer::VolumeRenderer() : impl_(std::make_unique<Impl>()) {}
+VolumeRenderer::~VolumeRenderer() = default;
+
+void VolumeRenderer::render() {
+    Impl& m = *impl_;
+    m.start();
+    m.allocate(camera.width, camera.height);
+    if (m.width <= 0) return;
+    const size_t px = (size_t)m.width * m.height;
+    uint8_t* frame = m.rgba[m.buf_index];
+    float* depth = m.depth[m.buf_index];
+    // glClearNamedFramebufferfv: colour = (b, b, b, 1) converted to RGBA8 the GL way
+    // (round(clamp(b, 0, 1) * 255)), depth attachment = 1e9 (cuda_renderer.cpp:85-92)
+    if (m.under_rgba) {
+        hip_check(hipMemcpyAsync(frame, m.under_rgba, px * 4, hipMemcpyDeviceToDevice, m.stream),
+                  "hipMemcpyAsync(underlay colour)");
+    } else {
+        const float b = std::min(std::max(options.background_brightness, 0.f), 1.f);
+        const uint32_t c = (uint32_t)std::lround(b * 255.f);
+        hip_check(hipMemsetD32Async((hipDeviceptr_t)frame, (int)(c | c << 8 | c << 16 | 0xFF000000u),
+                                    px, m.stream), "hipMemsetD32Async(frame)");
+    }
+    if (m.under_depth) {
+        hip_check(hipMemcpyAsync(depth, m.under_depth, px * 4, hipMemcpyDeviceToDevice, m.stream),
+                  "hipMemcpyAsync(underlay depth)");
+    } else {
+        const float inf = 1e9f;
+        uint32_t bits;
+        static_assert(sizeof(bits) == sizeof(inf), "");
+        __builtin_memcpy(&bits, &inf, 4);
+        hip_check(hipMemsetD32Async((hipDeviceptr_t)depth, (int)bits, px, m.stream),
+                  "hipMemsetD32Async(depth)");
+    }
+    camera._update();  // cuda_renderer.cpp:97
+    if (m.tree != nullptr)  // cuda_renderer.cpp:114-120: the interactive path composites (offscreen = false)
+        launch_renderer(*m.tree, camera, options, frame, depth, m.stream, false);
+    m.last = m.buf_index;
+    m.buf_index ^= 1;
+}
+
+void VolumeRenderer::set(N3Tree& tree) {  // cuda_renderer.cpp:171-180
+    impl_->start();
+    if (!tree.is_cuda_loaded())
+        throw std::runtime_error("VolumeRenderer::set: the tree is not on the device (N3Tree::open uploads it)");
+    impl_->tree = &tree;
+    options.basis_minmax[0] = 0;
+    options.basis_minmax[1] = std::max(tree.data_format.basis_dim - 1, 0);
+}
+
+void VolumeRenderer::clear() { impl_->tree = nullptr; }  // cuda_renderer.cpp:220
+
+void VolumeRenderer::resize(int width, int height) {  // cuda_renderer.cpp:128-169
+    if (camera.width == width && camera.height == height && impl_->width == width &&
+        impl_->height == height)
+        return;
+    impl_->start();
+    camera.width = width;
+    camera.height = height;
+    impl_->allocate(width, height);
+}
+
+const char* VolumeRenderer::get_backend() { return "HIP"; }  // upstream: "CUDA" (cuda_renderer.cpp:225)
+
+void VolumeRenderer::set_underlay(const void* rgba8_dev, const float* depth_dev) {
+    impl_->under_rgba = rgba8_dev;
+    impl_->under_depth = depth_dev;
+}
+
+const uint8_t* VolumeRenderer::frame() const {
+    return impl_->last < 0 ? nullptr : impl_->rgba[impl_->last];
+}
+
+void VolumeRenderer::read_frame(void* host_rgba8) {
+    Impl& m = *impl_;
+    if (m.last < 0) throw std::runtime_error("VolumeRenderer::read_frame: nothing rendered yet");
+    hip_check(hipMemcpyAsync(host_rgba8, m.rgba[m.last], (size_t)m.width * m.height * 4,
+                             hipMemcpyDeviceToHost, m.stream), "hipMemcpyAsync(read_frame)");
+    hip_check(hipStreamSynchronize(m.stream), "hipStreamSynchronize");
+}
+
+void* VolumeRenderer::stream() const { return impl_->stream; }
+
+}  // namespace volrend

@@ -38,8 +38,7 @@ int fail(int code, const char* fmt, ...) {
 struct Tuning {
     int march_max = 16;
     int refill_min = 24;
-    int refill_min_split = 12;  // the split kernel refills more eagerly (its march wave only loads 12 words per ray)
-    int flush_wait = 0;    // fused kernel: partial shade round once this many ended rays wait for colour (0 = off)
+    int flush_wait = 0;    // partial shade round once this many ended rays wait for colour (0 = off)
     int waves_per_cu = 0;   // 0: what the kernel flavour fits (vr_kernels.hip waves_per_cu<>)
     int frame_group = 0;   // poses per ray-order group (0 = all poses of the launch, 1 = frame-major)
     int super_block = 1;   // 8x8 blocks per super-block edge in the ray order
@@ -48,7 +47,6 @@ struct Tuning {
     int chunk_max = 4096;
     int top_levels = 0;    // lookup structure built at upload (vr_kernels.hip); 0 = auto
     int brick_levels = 3;
-    int split = -1;        // march / shade on separate waves: -1 = where it measures faster, 0 / 1 = forced
 };
 std::mutex g_tuning_mutex;
 Tuning& default_tuning_locked() {  // call with g_tuning_mutex held
@@ -65,7 +63,6 @@ Tuning& default_tuning_locked() {  // call with g_tuning_mutex held
         if (const char* e = getenv("VR_CHUNK_MAX")) x.chunk_max = atoi(e) < 64 ? 64 : (atoi(e) & ~63);
         if (const char* e = getenv("VR_TOP_LEVELS")) x.top_levels = atoi(e);
         if (const char* e = getenv("VR_BRICK_LEVELS")) x.brick_levels = atoi(e);
-        if (const char* e = getenv("VR_SPLIT")) x.split = atoi(e);
         return x;
     }();
     return tn;
@@ -77,7 +74,6 @@ Tuning default_tuning() {
 bool set_tuning_key(Tuning& tn, const char* key, int value) {
     if (!strcmp(key, "march_max")) tn.march_max = value < 1 ? 1 : value;
     else if (!strcmp(key, "refill_min")) tn.refill_min = value < 1 ? 1 : (value > 64 ? 64 : value);
-    else if (!strcmp(key, "refill_min_split")) tn.refill_min_split = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "flush_wait")) tn.flush_wait = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "waves_per_cu")) tn.waves_per_cu = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "frame_group")) tn.frame_group = value < 0 ? 0 : value;
@@ -87,7 +83,6 @@ bool set_tuning_key(Tuning& tn, const char* key, int value) {
     else if (!strcmp(key, "chunk_max")) tn.chunk_max = value < 64 ? 64 : (value & ~63);
     else if (!strcmp(key, "top_levels")) tn.top_levels = value;
     else if (!strcmp(key, "brick_levels")) tn.brick_levels = value;
-    else if (!strcmp(key, "split")) tn.split = value < 0 ? -1 : (value != 0);
     else return false;
     return true;
 }
@@ -339,16 +334,21 @@ struct PinnedSlot {
     bool used = false;
 };
 struct UploadCache {
+    static constexpr int kDevices = 16;
     std::mutex mu;
-    std::vector<PinnedSlot> free_slots;
-    hipStream_t stream[16] = {};  // per device, created on first use
-    bool take(PinnedSlot& out) {
+    // per DEVICE: a slot's event belongs to the device that was current when it was created, and
+    // recording it on another device's stream is an error
+    std::vector<PinnedSlot> free_slots[kDevices];
+    hipStream_t stream[kDevices] = {};  // per device, created on first use
+    // (call with `device` current)
+    bool take(PinnedSlot& out, int device) {
+        if (device < 0 || device >= kDevices) return false;
         {
             std::lock_guard<std::mutex> g(mu);
-            if (!free_slots.empty()) {
-                out = free_slots.back();
+            if (!free_slots[device].empty()) {
+                out = free_slots[device].back();
                 out.used = false;
-                free_slots.pop_back();
+                free_slots[device].pop_back();
                 return true;
             }
         }
@@ -362,9 +362,9 @@ struct UploadCache {
         out = sl;
         return true;
     }
-    void give(const PinnedSlot& sl) {
+    void give(const PinnedSlot& sl, int device) {
         std::lock_guard<std::mutex> g(mu);
-        free_slots.push_back(sl);
+        free_slots[device].push_back(sl);
     }
     // the stream and 2 x kCopyWorkersMax slots up front (first upload of the process)
     void warm(int device) {
@@ -372,14 +372,14 @@ struct UploadCache {
         std::vector<PinnedSlot> got;
         for (int i = 0; i < 2 * kCopyWorkersMax; ++i) {
             PinnedSlot sl;
-            if (!take(sl)) break;
+            if (!take(sl, device)) break;
             got.push_back(sl);
         }
-        for (const PinnedSlot& sl : got) give(sl);
+        for (const PinnedSlot& sl : got) give(sl, device);
     }
     hipStream_t stream_of(int device) {
         std::lock_guard<std::mutex> g(mu);
-        if (device < 0 || device >= 16) return nullptr;
+        if (device < 0 || device >= kDevices) return nullptr;
         if (!stream[device] &&
             hipStreamCreateWithFlags(&stream[device], hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError();
@@ -452,8 +452,8 @@ hipError_t staged_h2d_multi(const CopySegment* seg, int n_seg, int device) {
     std::atomic<size_t> next{0};
     auto work = [&]() {
         PinnedSlot slot[2];
-        bool ok = hipSetDevice(device) == hipSuccess && upload_cache().take(slot[0]) &&
-                  upload_cache().take(slot[1]);
+        bool ok = hipSetDevice(device) == hipSuccess && upload_cache().take(slot[0], device) &&
+                  upload_cache().take(slot[1], device);
         // chunks are claimed dynamically (a worker that was scheduled late does not hold the others up)
         for (int k = 0; ok; k ^= 1) {
             const size_t c = next.fetch_add(1);
@@ -468,12 +468,15 @@ hipError_t staged_h2d_multi(const CopySegment* seg, int n_seg, int device) {
             ok = hipMemcpyAsync(static_cast<char*>(seg[si].dst) + off, slot[k].mem, len,
                                 hipMemcpyHostToDevice, st) == hipSuccess &&
                  hipEventRecord(slot[k].done, st) == hipSuccess;
-            slot[k].used = true;
+            slot[k].used = ok;  // (only a RECORDED event may be waited for)
         }
+        // A failed enqueue / record may have left a DMA out of a slot in flight with no event to
+        // wait for: drain the stream before the slots go back to the cache.
+        if (!ok) (void)hipStreamSynchronize(st);
         for (auto& sl : slot) {
             if (!sl.mem) continue;
             if (sl.used && hipEventSynchronize(sl.done) != hipSuccess) ok = false;  // before the slot is reused
-            upload_cache().give(sl);
+            upload_cache().give(sl, device);
         }
         if (!ok) failed.store(1);
     };
@@ -984,7 +987,7 @@ int vr_tree_clone(vr_tree_t src, int device, vr_tree_t* out) {
     // no second pass over PCIe, no second re-layout
     // direct peer access (xGMI / PCIe P2P) when the two devices have it: hipMemcpyPeer then moves
     // the arrays device to device; without it the runtime stages them through host memory
-    // (still correct, ~10x slower) -- vr_last_error() keeps a note either way
+    // (still correct, ~10x slower) -- a note goes to stderr
     bool p2p = true;
     if (src->device != device) {
         int can = 0;
@@ -1020,9 +1023,9 @@ int vr_tree_clone(vr_tree_t src, int device, vr_tree_t* out) {
                     p2p ? "" : " (the devices have NO peer access: check `rocm-smi --showtopo`, "
                                "IOMMU / ACS settings and HSA_ENABLE_IPC_MODE_LEGACY=0)");
     }
-    if (!p2p)
-        (void)fail(VR_OK, "note: devices %d and %d have no peer access; the clone was staged "
-                          "through host memory", src->device, device);
+    if (!p2p)  // (a note, not an error: vr_last_error() stays empty after a call that returned VR_OK)
+        fprintf(stderr, "[volrend_hip] note: devices %d and %d have no peer access; the clone was "
+                        "staged through host memory\n", src->device, device);
     *out = t;
     return VR_OK;
 }
@@ -1286,6 +1289,14 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.any_accum = any_accum ? 1 : 0;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     std::unique_lock<std::mutex> guard(t->launch_mutex);
+    // vr_touch_enable / vr_touch_count (re)allocate these under the launch mutex: the launch must
+    // carry what is current NOW, not what fill_tree_params saw before the lock
+    auto refresh_instrumentation = [&]() {
+        k.status = t->status;
+        k.sched_stats = t->sched_stats;
+        for (int i = 0; i < 4; ++i) k.touch[i] = t->touch[i];
+    };
+    refresh_instrumentation();
     const Tuning tn = t->tn;  // (a copy: the mutex is dropped once below, while a slot grows)
     // lookup structure (top + bricks) beyond 4x the aggregate L2 (8 x 4 MiB on MI355X): the record
     // stream would keep evicting it -- see the DMA loads in vr_kernels.hip
@@ -1343,13 +1354,18 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
         guard.unlock();
         hipError_t ge = hipSuccess;
         if (old_rays) {
-            if (old_used) ge = hipEventSynchronize(ls.done);
-            if (ge == hipSuccess) ge = hipFree(old_rays);
+            // the slot's last launch must have finished before its buffer goes; if that wait
+            // fails the buffer is still freed (hipFree synchronises by itself): only a failing
+            // hipMalloc fails the call, and nothing is leaked either way
+            if (old_used) (void)hipEventSynchronize(ls.done);
+            (void)hipFree(old_rays);
+            (void)hipGetLastError();
         }
         uint32_t* new_rays = nullptr;
-        if (ge == hipSuccess) ge = hipMalloc((void**)&new_rays, need);
+        ge = hipMalloc((void**)&new_rays, need);
         guard.lock();
         ls.growing = false;
+        refresh_instrumentation();  // (the mutex was dropped: see above)
         if (ge != hipSuccess)
             return fail(ge == hipErrorOutOfMemory ? VR_ERR_OUT_OF_MEMORY : VR_ERR_HIP,
                         "ray buffer of %zu bytes: %s", need, hipGetErrorString(ge));
@@ -1394,19 +1410,7 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
         }
         HIP_TRY(vr::launch_prepare(k, tbl, hs));
     }
-    // Kernel organisation of the FAST flavours (vr_kernels.hip): ONE frame per launch -- the
-    // reference's launch_renderer contract -- is a latency-bound job (about one ray per resident
-    // lane, the frame takes as long as its longest ray): there the split kernel (march and shade
-    // on separate waves, 8 waves per SIMD, rays retired without waiting for their colour) is
-    // 10 % faster (C1 0.56 against 0.63 ms, C3 1.20 against 1.33).  Batches are throughput-bound
-    // and the split kernel executes ~30 % more instructions for the same work: fused wins from 2
-    // frames on (profiles/r03_split_vs_fused.jsonl).  SH25's shade state does not fit the split
-    // kernel's register budget at all.
-    const int split = tn.split >= 0 ? tn.split : (n_frames == 1 && t->desc.basis_dim != 25);
-    const bool fast_n2 = t->desc.N == 2 && t->top_levels > 0 && !instrumented && !k.render_depth &&
-                         t->desc.format != VR_FORMAT_SG && t->desc.format != VR_FORMAT_ASG;
-    if (split && fast_n2) k.refill_min = tn.refill_min_split;  // (only the FAST flavours have a split form)
-    HIP_TRY(vr::launch_render(k, f->fp_mode, t->n_cus, tn.waves_per_cu, split, hs));
+    HIP_TRY(vr::launch_render(k, f->fp_mode, t->n_cus, tn.waves_per_cu, hs));
     return VR_OK;  // (`seal` records the slot's event)
 }
 

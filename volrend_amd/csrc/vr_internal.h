@@ -91,7 +91,7 @@ struct KParams {
     int32_t basis_words;         // basis_fn words per ray in ray_buf (0 for RGBA)
     int32_t refill_min;          // refill once this many lanes are idle
     int32_t march_max;           // march steps per lane between two shade checks
-    int32_t flush_wait;          // fused kernel: shade a partial round once this many ended rays wait for colour (0 = never)
+    int32_t flush_wait;          // shade a partial round once this many ended rays wait for colour (0 = never)
     int32_t instrumented;        // any frame carries counters -> FULL flavour
     int32_t any_accum;           // some frame of the launch asks for its fp32 accumulators
     int32_t records_nt;          // record DMA loads carry the non-temporal hint (large lookup structures)
@@ -106,8 +106,7 @@ struct KParams {
 
 // vr_kernels.hip
 hipError_t launch_prepare(const KParams& p, const FrameTable& tbl, hipStream_t stream);
-// split != 0: the FAST flavours run march and shade on separate waves (render_ms_kernel)
-hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_override, int split,
+hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_override,
                          hipStream_t stream);
 hipError_t launch_assemble(uint8_t* frame, int64_t pitch, const uint8_t* gathered, int width,
                            int height, int tile_w, int tile_h, int world, int n_frames,

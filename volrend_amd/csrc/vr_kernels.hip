@@ -7,7 +7,7 @@
 // from the algorithm, not from the CUDA text: wave64 8x8 pixel tiles, a device
 // re-layout built at upload (sigma packed into the node words, padded 16-byte
 // aligned SH records, a top grid + bricks lookup structure), integer digit descent for N=2
-// (bit-identical to the float descent, see query_n2), march/shade phase split,
+// (bit-identical to the float descent, see query_n2), march / shade phases,
 // deterministic expf, explicit FP contraction policy.
 //
 // Built with -ffp-contract=off; see vr_device_math.h.
@@ -19,199 +19,11 @@ namespace vr {
 namespace {
 
 constexpr int kWave = 64;
-// ===========================================================================
-// EXPERIMENT HOOKS.  Everything between these two fences exists for timing experiments and
-// profiling builds (tools/*.sh, profiles/*): -DVR_ABLATE=n removes work ON PURPOSE (wrong
-// pictures, never shipped -- the build script refuses to install such a library as the
-// product), -DVR_TIMELINE=n adds shader-clock reads around the phases.  The product build
-// (both 0) gets the first branch of each #if: plain expressions and empty statements.  The
-// kernels below only use the VR_EXP_* / TL_* names.
-// ===========================================================================
-#ifndef VR_ABLATE
-#define VR_ABLATE 0
-#endif
-#ifndef VR_TIMELINE
-#define VR_TIMELINE 0  // 1: per-phase cycle sums into sched_stats; 2: + march-round breakdown (split kernel);
-                       // 3: time-resolved tallies of a launch instead (fused kernel)
-#endif
-#if VR_ABLATE == 0
-#define VR_EXP_RECORD_CHUNK(v, j, leaf) ((v)[j])   // 16-byte chunk j of a record (register path)
-#define VR_EXP_RECORD_LEAF(leaf) (leaf)            // the record an item names (DMA path)
-#define VR_EXP_RECORD_DMA 1                        // record DMAs are issued
-#define VR_EXP_FUSED_COLOUR 1                      // fused kernel: hit samples queue colour work
-#define VR_EXP_SPLIT_COLOUR 1                      // split kernel: the shade wave does its colour work
-#define VR_EXP_STEAL 1                             // waves steal from the ray queues of other XCDs
-#else
-#define VR_EXP_RECORD_CHUNK(v, j, leaf) \
-    (VR_ABLATE == 1 ? (v)[0] : VR_ABLATE == 2 ? make_uint4((leaf) + (j), (leaf), (leaf), (leaf)) : (v)[j])
-#define VR_EXP_RECORD_LEAF(leaf) (VR_ABLATE == 5 ? ((leaf) & 0x3FFu) : (leaf))  // 5: a 128 KB window
-#define VR_EXP_RECORD_DMA (VR_ABLATE != 4)         // 4: no record fetch at all
-#define VR_EXP_FUSED_COLOUR (VR_ABLATE != 6)       // 6: fused kernel marches without colour work
-#define VR_EXP_SPLIT_COLOUR (VR_ABLATE != 7)       // 7: the shade wave only consumes its items
-#define VR_EXP_STEAL (VR_ABLATE != 8)              // 8: every wave stays with the ray queue of its XCD (same pictures)
-#endif
-#if VR_TIMELINE == 1 || VR_TIMELINE == 2
-#define TL_MARK() (tl_mark = __builtin_readcyclecounter())
-#define TL_ADD(v) do { const unsigned long long n_ = __builtin_readcyclecounter(); \
-                       (v) += n_ - tl_mark; tl_mark = n_; } while (0)
-#elif VR_TIMELINE == 3
-#define TL_MARK() (tl3_mark = (uint32_t)__builtin_readcyclecounter())
-#define TL_ADD(v) TL3_TIME(TL3_IDX_##v)
-#else
-#define TL_MARK() ((void)0)
-#define TL_ADD(v) ((void)0)
-#endif
-#if VR_TIMELINE == 2
-#define TL2_MARK() (tl2_mark = __builtin_readcyclecounter())
-#define TL2_ADD(v) do { const unsigned long long n_ = __builtin_readcyclecounter(); \
-                        (v) += n_ - tl2_mark; tl2_mark = n_; } while (0)
-#define TL2_COUNT(go_) do { tl2_rounds++; tl2_lanes += (unsigned long long)__builtin_popcountll( \
-                            __builtin_amdgcn_ballot_w64(go_)); } while (0)
-#else
-#define TL2_MARK() ((void)0)
-#define TL2_ADD(v) ((void)0)
-#define TL2_COUNT(go_) ((void)0)
-#endif
-#if VR_TIMELINE == 3
-// time-resolved tallies of the fused kernel: per bucket of 2^15 shader clocks (14.9 us at
-// 2.2 GHz; 64 buckets, counted from the start of the wave -- the waves of a persistent launch
-// all start within ~20 us) the cycles spent in the retire / refill block, marching and shading,
-// the march rounds, the marching lanes, and the waves that ended.  A wave counts in 768 bytes of
-// its LDS (two scalar registers of state: the kernel has none to spare) and adds its table to
-// one of 64 global copies when it ends; read (and cleared) by vr_exp_tl3_read() --
-// tools/tail_profile.py.
-constexpr int kTl3Buckets = 64, kTl3Copies = 64, kTl3Rows = 6;
-__device__ unsigned long long vr_tl3[kTl3Copies][kTl3Rows][kTl3Buckets];
-#define TL3_IDX_tl_refill 0
-#define TL3_IDX_tl_march 1
-#define TL3_IDX_tl_shade_load 2
-#define TL3_IDX_tl_shade_math 2
-#define TL3_IDX_tl_shade_acc 2
-#define TL3_IDX_tl_m_march (-1)  // (the split kernel is not instrumented in this mode)
-#define TL3_IDX_tl_m_refill (-1)
-#define TL3_IDX_tl_m_stall (-1)
-#define TL3_IDX_tl_s_dma (-1)
-#define TL3_IDX_tl_s_event (-1)
-#define TL3_IDX_tl_s_idle (-1)
-#define TL3_IDX_tl_s_math (-1)
-#define TL3_BUCKET(now_) ((((now_) - tl3_clk0) >> 15) & (uint32_t)(kTl3Buckets - 1))
-#define TL3_DECL() __shared__ uint32_t tl3_h[3 * kTl3Buckets];                                      \
-                   for (int k_ = threadIdx.x & 63; k_ < 3 * kTl3Buckets; k_ += 64) tl3_h[k_] = 0;   \
-                   __syncthreads();                                                                 \
-                   const uint32_t tl3_clk0 = (uint32_t)__builtin_readcyclecounter();                \
-                   uint32_t tl3_mark = tl3_clk0
-// words of a bucket: [0] refill | march << 16 (units of 16 clocks), [1] shade | rounds << 16, [2] lanes
-#define TL3_TIME(idx_) do { const uint32_t n_ = (uint32_t)__builtin_readcyclecounter();              \
-        const uint32_t d_ = (n_ - tl3_mark) >> 4; tl3_mark = n_;                                     \
-        if ((idx_) >= 0 && lane == 0)                                                               \
-            atomicAdd(&tl3_h[3 * TL3_BUCKET(n_) + ((idx_) >> 1)], d_ << (16 * ((idx_) & 1))); } while (0)
-#define TL3_ROUND(go_) do { const uint32_t l_ = (uint32_t)__builtin_popcountll(                       \
-                                __builtin_amdgcn_ballot_w64(go_));                                  \
-        if (lane == 0) { const uint32_t b_ = TL3_BUCKET((uint32_t)__builtin_readcyclecounter());    \
-                         atomicAdd(&tl3_h[3 * b_ + 1], 1u << 16); atomicAdd(&tl3_h[3 * b_ + 2], l_); } } while (0)
-#define TL3_SHADE(n_) ((void)0)
-#define TL3_END() do { __syncthreads();                                                             \
-        unsigned long long(*h_)[kTl3Buckets] = vr_tl3[blockIdx.x % kTl3Copies];                     \
-        const uint32_t a_ = tl3_h[3 * lane], b_ = tl3_h[3 * lane + 1], c_ = tl3_h[3 * lane + 2];    \
-        if (a_ | b_ | c_) {                                                                         \
-            atomicAdd(&h_[0][lane], (unsigned long long)(a_ & 0xFFFFu));                            \
-            atomicAdd(&h_[1][lane], (unsigned long long)(a_ >> 16));                                \
-            atomicAdd(&h_[2][lane], (unsigned long long)(b_ & 0xFFFFu));                            \
-            atomicAdd(&h_[3][lane], (unsigned long long)(b_ >> 16));                                \
-            atomicAdd(&h_[4][lane], (unsigned long long)c_);                                        \
-        }                                                                                           \
-        if (lane == 0) atomicAdd(&h_[5][TL3_BUCKET((uint32_t)__builtin_readcyclecounter())], 1ull); } while (0)
-#else
-#define TL3_DECL() ((void)0)
-#define TL3_ROUND(go_) ((void)0)
-#define TL3_SHADE(n_) ((void)0)
-#define TL3_END() ((void)0)
-#endif
-// declarations / dumps of the cycle tallies (sched_stats words: see tools/quick_ab.py, bench.py)
-#if VR_TIMELINE == 1 || VR_TIMELINE == 2
-#define TL_DECL_FUSED()                                                                          \
-    unsigned long long tl_refill = 0, tl_march = 0, tl_shade_load = 0, tl_shade_math = 0,        \
-                       tl_shade_acc = 0, tl_total0 = __builtin_readcyclecounter(), tl_mark = 0,  \
-                       tl_drained = 0 /* when this wave found the ray queue empty */
-#define TL_QUEUE_DRY() (tl_drained = __builtin_readcyclecounter())
-#define TL_DUMP_FUSED()                                                                           \
-    do {                                                                                          \
-        if (!COUNT && p.sched_stats && lane == 0) {                                               \
-            atomicAdd(&p.sched_stats[0], tl_refill);                                              \
-            atomicAdd(&p.sched_stats[1], tl_march);                                               \
-            atomicAdd(&p.sched_stats[2], tl_shade_load);                                          \
-            atomicAdd(&p.sched_stats[3], tl_shade_math);                                          \
-            atomicAdd(&p.sched_stats[4], tl_shade_acc);                                           \
-            atomicAdd(&p.sched_stats[5], (unsigned long long)__builtin_readcyclecounter() - tl_total0); \
-            atomicAdd(&p.sched_stats[6], 1ull);                                                   \
-            /* the wave's tail: from the moment the queue was empty to its last retired ray */    \
-            atomicAdd(&p.sched_stats[7], (unsigned long long)__builtin_readcyclecounter() - tl_drained); \
-        }                                                                                         \
-    } while (0)
-#define TL_DECL_MARCH()                                                                           \
-    unsigned long long tl_mark = __builtin_readcyclecounter(), tl_m_refill = 0, tl_m_march = 0,   \
-                       tl_m_stall = 0, tl2_mark = 0, tl2_peek = 0, tl2_query = 0, tl2_push = 0,   \
-                       tl2_rounds = 0, tl2_lanes = 0;                                             \
-    (void)tl2_mark, (void)tl2_peek, (void)tl2_query, (void)tl2_push, (void)tl2_rounds, (void)tl2_lanes
-#define TL_DECL_SHADE()                                                                           \
-    unsigned long long tl_mark = __builtin_readcyclecounter(), tl_s_idle = 0, tl_s_event = 0,     \
-                       tl_s_dma = 0, tl_s_math = 0, tl2_chunks = 0, tl2_items = 0
-#define TL_SHADE_CHUNK(n_) do { tl2_chunks++; tl2_items += (unsigned long long)(n_); } while (0)
-#if VR_TIMELINE == 2
-#define TL_DUMP_MARCH()                                                                           \
-    do {                                                                                          \
-        if (p.sched_stats && lane == 0) {                                                         \
-            atomicAdd(&p.sched_stats[0], tl2_peek);                                               \
-            atomicAdd(&p.sched_stats[1], tl2_query);                                              \
-            atomicAdd(&p.sched_stats[2], tl2_push);                                               \
-            atomicAdd(&p.sched_stats[3], tl2_rounds);                                             \
-            atomicAdd(&p.sched_stats[4], tl2_lanes);                                              \
-            atomicAdd(&p.sched_stats[7], 1ull);                                                   \
-        }                                                                                         \
-    } while (0)
-#define TL_DUMP_SHADE()                                                                           \
-    do {                                                                                          \
-        if (p.sched_stats && lane == 0) {                                                         \
-            atomicAdd(&p.sched_stats[5], tl2_chunks);                                             \
-            atomicAdd(&p.sched_stats[6], tl2_items);                                              \
-        }                                                                                         \
-    } while (0)
-#else
-#define TL_DUMP_MARCH()                                                                           \
-    do {                                                                                          \
-        if (p.sched_stats && lane == 0) {                                                         \
-            atomicAdd(&p.sched_stats[0], tl_m_refill);                                            \
-            atomicAdd(&p.sched_stats[1], tl_m_march);                                             \
-            atomicAdd(&p.sched_stats[2], tl_m_stall);                                             \
-            atomicAdd(&p.sched_stats[7], 1ull);                                                   \
-        }                                                                                         \
-    } while (0)
-#define TL_DUMP_SHADE()                                                                           \
-    do {                                                                                          \
-        if (p.sched_stats && lane == 0) {                                                         \
-            atomicAdd(&p.sched_stats[3], tl_s_idle);                                              \
-            atomicAdd(&p.sched_stats[4], tl_s_event);                                             \
-            atomicAdd(&p.sched_stats[5], tl_s_dma);                                               \
-            atomicAdd(&p.sched_stats[6], tl_s_math);                                              \
-        }                                                                                         \
-    } while (0)
-#endif
-#else
-#define TL_DECL_FUSED() ((void)0)
-#define TL_QUEUE_DRY() ((void)0)
-#define TL_DUMP_FUSED() ((void)0)
-#if VR_TIMELINE == 3
-#define TL_DECL_MARCH() uint32_t tl3_mark = 0; const uint32_t tl3_clk0 = 0; uint32_t* const tl3_h = nullptr
-#define TL_DECL_SHADE() uint32_t tl3_mark = 0; const uint32_t tl3_clk0 = 0; uint32_t* const tl3_h = nullptr
-#else
-#define TL_DECL_MARCH() ((void)0)
-#define TL_DECL_SHADE() ((void)0)
-#endif
-#define TL_SHADE_CHUNK(n_) ((void)0)
-#define TL_DUMP_MARCH() ((void)0)
-#define TL_DUMP_SHADE() ((void)0)
-#endif
-// ========================= end of the experiment hooks =====================
+// Experiment hooks (timing ablations, shader-clock timelines): macros that expand to the plain
+// expression / nothing in the product build.
+#define VR_HOOKS_PART 1
+#include "vr_experiment_hooks.h"
+#undef VR_HOOKS_PART
 #ifndef VR_MIN_WAVES_PER_EU
 #define VR_MIN_WAVES_PER_EU 8  // cap on the per-flavour register bounds (experiments)
 #endif
@@ -230,12 +42,6 @@ __device__ unsigned long long vr_tl3[kTl3Copies][kTl3Rows][kTl3Buckets];
 #endif
 #ifndef VR_SH9_WAVES
 #define VR_SH9_WAVES 6  // (7 fits the LDS but needs 72 VGPRs: scratch)
-#endif
-#ifndef VR_MS_SH16_WAVES
-#define VR_MS_SH16_WAVES 8   // split kernel (render_ms_kernel): both roles within 64 VGPRs
-#endif
-#ifndef VR_MS_SH9_WAVES
-#define VR_MS_SH9_WAVES 8
 #endif
 #ifndef VR_PACKED_EXP
 #define VR_PACKED_EXP 1       // the sigmoids of channels 0/1 share packed mul / fma / add instructions
@@ -562,29 +368,6 @@ __device__ __forceinline__ void load_record(const KParams& p, uint32_t leaf, Rec
 // SH / SG colour of channel c: rt_core.cuh:125-165.  Group order 25 -> 16 -> 9
 // -> 4, each group summed left to right, then added to tmp.  Coefficient e of the record is
 // half (e & 1) of word e >> 1; products read it in place (mul_half / fma_half).
-// The 16-byte chunks of a staged record (LDS row) that hold channel C's coefficients.
-template <int BASIS, int C>
-struct ChanWin {
-    static constexpr int kFirst = (C * BASIS) / 8;
-    static constexpr int kLast = (C * BASIS + BASIS - 1) / 8;
-    static constexpr int kChunks = kLast - kFirst + 1;
-    uint32_t w[kChunks * 4];
-    __device__ __forceinline__ void load(const char* row) {
-#pragma unroll
-        for (int q = 0; q < kChunks; ++q) {
-            const uint4 v = *reinterpret_cast<const uint4*>(row + (kFirst + q) * 16);
-            w[4 * q + 0] = v.x;
-            w[4 * q + 1] = v.y;
-            w[4 * q + 2] = v.z;
-            w[4 * q + 3] = v.w;
-        }
-    }
-    template <int E>
-    __device__ __forceinline__ uint32_t word() const {
-        return w[(E >> 1) - kFirst * 4];
-    }
-};
-
 template <int E, typename SRC>
 __device__ __forceinline__ float coef_mul(float b, const SRC& r) {
     return mul_half<E & 1>(b, r.template word<E>());
@@ -612,7 +395,7 @@ struct DotGroup {
     }
 };
 
-// SRC = Record<BASIS> (whole record in registers) or ChanWin<BASIS, C> (channel window)
+// SRC = Record<BASIS> (whole record in registers) or GroupWin (words of a staged record)
 template <int FMA, int BASIS, int C, typename SRC>
 __device__ __forceinline__ float channel_dot(const float* basis_fn, const SRC& r) {
     static_assert(BASIS > 1, "SH / SG / ASG sizes only");
@@ -650,8 +433,8 @@ template <int FMA, int BASIS, int LO, int HI, bool FENCE, typename GET>
 __device__ __forceinline__ void add_group(const char* row, GET&& get, float* acc) {
     float b[VR_MAX_BASIS];
     // FENCE keeps the scheduler from hoisting the next group's fetches over this group's
-    // arithmetic (lowest register use, but every group then waits for its own LDS round trip):
-    // the shade wave of the split kernel, whose budget is 64 registers and which has time to spare
+    // arithmetic (lowest register use, but every group then waits for its own LDS round trip;
+    // experiments with tighter register budgets: VR_SHADE_SCHED_BARRIER)
     if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = LO; i <= HI; ++i) b[i] = get(i);
@@ -733,7 +516,6 @@ __device__ __forceinline__ bool wave_any(bool v) { return __builtin_amdgcn_ballo
 //   * Finished rays composite over the background, quantise and store their
 //     pixel -- retired and refilled in batches of >= refill_min lanes, one memory round
 //     trip per batch.
-//   (render_ms_kernel further down runs the same two phases on separate waves.)
 // Per-ray arithmetic and its order are exactly the reference's.
 // ---------------------------------------------------------------------------
 struct Ray {
@@ -1561,558 +1343,6 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
 
 
 // ---------------------------------------------------------------------------
-// render_ms_kernel: the FAST flavours with the march and the shade phase on SEPARATE waves.
-//
-// render_kernel above alternates the two phases inside one wave, so the wave's march loads
-// are not in flight while it shades (march = 62 % of a C1 wave's life) and its register
-// allocation is the union of both phases' state (SH16: 96 VGPRs = 5 waves per SIMD).  Here a
-// workgroup is a PAIR of waves that talk through LDS only:
-//   wave 0 "march" : owns 64 rays (rt_core.cuh:108-188 without the colour arithmetic): position,
-//       lookup, attenuation, light, stop test.  A hit sample becomes an item (leaf, weight,
-//       owner lane, per-lane sequence number) in an LDS ring.  A finished ray is retired AT ONCE
-//       (no wait for its colour) through an event: (light, stopped, id of the lane's next ray).
-//       No basis, no colour state, no shade temporaries: ~45 VGPRs.
-//   wave 1 "shade" : lane j keeps the colour state of march lane j's ray (out[3], basis_fn, the
-//       ray's id).  It consumes the ring in order, 64 items at a time -- record DMA, SH
-//       arithmetic, sigmoid exactly as shade_chunk above -- adds each lane's contributions in
-//       sequence order (= sample order, rt_core.cuh:161), and on an event composites /
-//       quantises / stores the finished pixel and loads the next ray's basis.
-// The march wave never waits for colour work unless the ring is full or one ray has
-// kMsOutstanding items in flight; the shade wave has slack (its phases were 35 % of the fused
-// wave's time).  Per-ray arithmetic and its order are unchanged, so the results are the same bits.
-//
-// LDS protocol (single producer, single consumer; every word has exactly one writer):
-//   it_leaf / it_w / it_own[kMsRing]  ring entries, written by march before `tail` moves past them
-//   tail   (march -> shade)  entries [head, tail) are valid
-//   head   (shade -> march)  entries below head are free
-//   cons[64] (shade -> march) items of lane j consumed so far (mod 256): lane j may push while
-//            pushed - cons < kMsOutstanding, which bounds the per-owner table below
-//   ev_*   (march -> shade)  payload of ONE event batch; the batch takes one ring position
-//            (ev_mask[2]; the entry itself carries nothing) so that it is handled in order with
-//            the items.  march posts the next batch only after ev_done caught up.
-//   flags  (march -> shade)  bit0: march is waiting for the shade wave (shade a partial chunk
-//            instead of waiting for 64 items), bit1: march has finished.
-// Both waves only ever spin on the OTHER wave of their own workgroup (co-resident by
-// construction); march-side waits are bounded and trip the status word instead of hanging.
-// ---------------------------------------------------------------------------
-#ifndef VR_MS_SLEEP
-#define VR_MS_SLEEP 4   // s_sleep argument of the shade wave's idle poll (x 64 cycles)
-#endif
-#ifndef VR_MS_RING
-#define VR_MS_RING 256
-#endif
-#ifndef VR_MS_MIN_CHUNK
-#define VR_MS_MIN_CHUNK 64  // items the shade wave waits for while the march wave is producing
-#endif
-constexpr int kMsRing = VR_MS_RING;   // ring entries (positions are compared mod 2^32)
-constexpr int kMsOutstanding = 8;     // items one lane may have in the ring
-constexpr uint32_t kMsNoRay = 0x7FFFFFFFu;
-constexpr uint32_t kMsSpinCap = 1u << 22;  // polls before a march-side wait gives up (~0.3 s): status bit 1
-
-__device__ __forceinline__ void lds_fence() {  // LDS accesses of this wave issued so far are done
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-__device__ __forceinline__ void mem_fence() {  // ... and its global loads / LDS-DMAs have landed
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-}
-// the protocol words are read / written as plain volatile LDS dwords (address space 3: no generic
-// pointer, no address-space test in the generated code)
-typedef __attribute__((address_space(3))) volatile uint32_t vr_lds_word_t;
-#define lds_peek(var) (*(const vr_lds_word_t*)&(var))
-#define lds_post(var, v) (*(vr_lds_word_t*)&(var) = (v))
-
-// Register budget per flavour (waves per SIMD; a pair needs two).
-template <int BASIS>
-constexpr int ms_min_waves() {
-    return BASIS == BASIS_25 ? 4 : BASIS == BASIS_16 ? VR_MS_SH16_WAVES : BASIS == BASIS_9 ? VR_MS_SH9_WAVES : 8;
-}
-template <int BASIS>
-constexpr int ms_lds_bytes() {
-    return kMsRing * 10 + Stage<BASIS>::kBytes + kWave * (1 + kMsOutstanding + 8) + 64;
-}
-template <int BASIS>
-constexpr int ms_pairs_per_cu() {
-    const int lds = ((ms_lds_bytes<BASIS>() + 511) / 512) * 512;
-    const int by_lds = 163840 / lds, by_reg = 2 * ms_min_waves<BASIS>();
-    return by_lds < by_reg ? by_lds : by_reg;
-}
-
-template <int FMA, int BASIS>
-__global__ __launch_bounds__(2 * kWave, (ms_min_waves<BASIS>())) void render_ms_kernel(
-    const KParams p) {
-    using P = Policy<FMA>;
-    constexpr int NB = BASIS > 1 ? BASIS : 1;
-    constexpr bool HAS_BASIS = BASIS != BASIS_RGBA;
-    constexpr uint32_t RM = kMsRing - 1;
-    using ST = Stage<BASIS>;
-    __shared__ uint32_t it_leaf[kMsRing];
-    __shared__ float it_w[kMsRing];
-    __shared__ uint16_t it_own[kMsRing];  // owner lane | (sequence number & 7) << 8
-    // c_status[0] = tail, c_status[1] = flags | ev_posted << 8: one 8-byte read shows the shade
-    // wave everything the march wave publishes
-    __shared__ __attribute__((aligned(8))) uint32_t c_status[2];
-    __shared__ uint32_t c_head, c_ev_done;
-    __shared__ uint32_t ev_mask[3];       // lanes of the batch (2 words), ring position of the batch
-    __shared__ float ev_light[kWave];
-    __shared__ uint32_t ev_word[kWave];   // id of the lane's next ray (kMsNoRay: none) | stopped << 31
-    __shared__ uint8_t cons[kWave];
-    __shared__ __attribute__((aligned(8))) uint8_t table[kWave][kMsOutstanding];
-    __shared__ __attribute__((aligned(16))) char stage[ST::kBytes];
-
-    const int lane = threadIdx.x & (kWave - 1);
-    if (threadIdx.x == 0) {
-        c_status[0] = 0u;
-        c_status[1] = 0u;
-        c_head = 0u;
-        c_ev_done = 0u;
-    }
-    if (threadIdx.x < kWave) {
-        cons[lane] = 0;
-        *reinterpret_cast<unsigned long long*>(table[lane]) = ~0ull;
-    }
-    __syncthreads();  // the only barrier: from here on the two waves run asynchronously
-    const int wpr = kRayWords + p.basis_words;
-    // (the hardware spreads the waves of the workgroups evenly over the four SIMDs of a CU --
-    // measured with HW_ID: each SIMD holds as many march waves as shade waves)
-    const bool is_march = threadIdx.x < (unsigned)kWave;
-
-    if (is_march) {
-        // =========================== march wave ===========================
-        float cen[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 0.f}, invdir[3] = {1.f, 1.f, 1.f};
-        float t = 0.f, tmax = -1.f, delta_scale = 1.f, light = 1.f;
-        bool active = false, alive = false, stopped = false;
-        Cursor cur;
-        uint32_t pushed = 0;  // items this LANE has pushed so far (all its rays; compared mod 256)
-        uint32_t tail = 0, ev_posted = 0;
-        uint32_t rounds = 0, progress_round = 0;
-        bool exhausted = false, aborted = false;
-        uint32_t chunk_next = 0, chunk_end = 0;
-        const uint32_t total = *p.ray_count;
-        uint32_t flags_now = 0;
-        TL_DECL_MARCH();
-        auto give_up = [&]() {  // a wait on the shade wave ran into its cap: report, stop
-            if (p.status) atomicOr(p.status, 2u);
-            aborted = true;
-        };
-
-        // One flat loop with a single exit: per iteration an optional refill, then ONE march round
-        // or one poll of the shade wave.  (Nested loops with breaks / continues cost this wave
-        // dozens of scalar instructions per round in exit bookkeeping -- the compiler turns them
-        // into a state machine -- and the scalar unit is shared by the CU's four SIMDs.)
-        bool running = true;
-        uint32_t spins = 0, m_left = 0;  // rounds until the refill conditions are looked at again
-        while (running) {
-            TL_ADD(tl_m_march);
-            // ---- retire finished rays, hand their lanes new ones ----
-            // (looked at every march_max rounds, and whenever no lane can march)
-            const bool look = m_left == 0u;
-            m_left = __builtin_amdgcn_readfirstlane(look ? (uint32_t)p.march_max : m_left) - 1u;
-            const bool done = active && !alive;
-            unsigned long long m_done = 0ull, m_free = 0ull, m_live = 1ull;
-            int n_avail = 0;
-            if (look) {
-                m_done = __builtin_amdgcn_ballot_w64(done);
-                m_free = __builtin_amdgcn_ballot_w64(!active);
-                m_live = __builtin_amdgcn_ballot_w64(active && alive);
-                n_avail = __builtin_popcountll(m_done | m_free);
-            }
-            if (n_avail > 0 && (m_live == 0ull || (!exhausted && n_avail >= p.refill_min))) {
-                progress_round = rounds;
-                if (!exhausted && chunk_next >= chunk_end) {  // (same queue protocol as render_kernel)
-                    uint32_t lo, hi;
-                    grab_chunk(p, total, lane, lo, hi);
-                    lo = __builtin_amdgcn_readfirstlane(lo);
-                    hi = __builtin_amdgcn_readfirstlane(hi);
-                    if (hi == lo) {
-                        exhausted = true;
-                    } else {
-                        chunk_next = lo;
-                        chunk_end = hi;
-                    }
-                }
-                const bool vacant = done || !active;
-                bool take = false;
-                uint32_t r = 0;
-                if (!exhausted) {
-                    const unsigned long long idle = m_done | m_free;
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
-                        (uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                    r = chunk_next + rank;
-                    const uint32_t left = chunk_end - chunk_next;
-                    take = vacant && r < chunk_end;
-                    chunk_next += (uint32_t)n_avail < left ? (uint32_t)n_avail : left;
-                }
-                // the new rays are requested first, the event is posted while they travel
-                if (take) {
-                    const uint32_t* rs = ray_slot(p.ray_buf, wpr, r);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        cen[i] = u2f(ray_word(rs, 0 + i));
-                        dir[i] = u2f(ray_word(rs, 3 + i));
-                        invdir[i] = u2f(ray_word(rs, 6 + i));
-                    }
-                    t = u2f(ray_word(rs, 9));
-                    tmax = u2f(ray_word(rs, 10));
-                    delta_scale = u2f(ray_word(rs, 11));
-                }
-                const bool ev = done || take;
-                const unsigned long long m_ev = __builtin_amdgcn_ballot_w64(ev);
-                if (m_ev != 0ull) {
-                    // one event batch at a time: the shade wave must have taken the previous one,
-                    // and the ring needs a free entry for the marker
-                    uint32_t ev_spins = 0;
-                    while (!aborted && (lds_peek(c_ev_done) != ev_posted ||
-                                        tail - lds_peek(c_head) >= (uint32_t)kMsRing)) {
-                        if (!(flags_now & 1u)) {
-                            flags_now = __builtin_amdgcn_readfirstlane(flags_now | 1u);
-                            if (lane == 0) lds_post(c_status[1], flags_now | (ev_posted << 8));
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++ev_spins > kMsSpinCap) give_up();
-                    }
-                    if (ev) {
-                        ev_light[lane] = light;
-                        ev_word[lane] = (take ? r : kMsNoRay) | ((done && stopped) ? 0x80000000u : 0u);
-                    }
-                    if (lane == 0) {
-                        ev_mask[0] = (uint32_t)m_ev;
-                        ev_mask[1] = (uint32_t)(m_ev >> 32);
-                        ev_mask[2] = tail;  // the batch's place in the ring (its entry carries nothing)
-                    }
-                    lds_fence();
-                    tail = __builtin_amdgcn_readfirstlane(tail + 1u);
-                    ev_posted = __builtin_amdgcn_readfirstlane(ev_posted + 1u);
-                    if (lane == 0) {
-                        // "a batch is pending" becomes visible BEFORE the tail that covers its ring
-                        // position: the shade wave must never take that position for an item
-                        lds_post(c_status[1], flags_now | (ev_posted << 8));
-                        lds_post(c_status[0], tail);
-                    }
-                }
-                if (vacant) {
-                    active = alive = take;
-                    light = 1.f;
-                    stopped = false;
-                    cur = Cursor();
-                }
-            }
-            // ---- march one round, or wait for the shade wave ----
-            TL_ADD(tl_m_refill);
-            const bool want = active && alive;
-            const uint32_t c = *(const __attribute__((address_space(3))) volatile uint8_t*)&cons[lane];
-            const uint32_t head = __builtin_amdgcn_readfirstlane(lds_peek(c_head));
-            const bool go = want && ((pushed - c) & 0xFFu) < (uint32_t)kMsOutstanding;
-            const bool any_want = wave_any(want);
-            const bool blocked =
-                any_want && (!wave_any(go) || tail - head > (uint32_t)(kMsRing - kWave));
-            TL2_MARK();
-            if (!any_want) {
-                // nothing to march: either the next iteration refills, or this wave is done
-                m_left = 0u;
-                if (exhausted && !wave_any(active)) running = false;
-            } else if (blocked) {
-                // every marching ray has kMsOutstanding items in flight, or the ring is full:
-                // tell the shade wave not to wait for a full chunk, and poll
-                if (!(flags_now & 1u)) {
-                    flags_now = __builtin_amdgcn_readfirstlane(flags_now | 1u);
-                    if (lane == 0) lds_post(c_status[1], flags_now | (ev_posted << 8));
-                }
-                TL_ADD(tl_m_march);
-                __builtin_amdgcn_s_sleep(1);
-                spins = __builtin_amdgcn_readfirstlane(spins + 1u);
-                if (spins > kMsSpinCap) give_up();
-                TL_ADD(tl_m_stall);
-            } else {
-                TL2_COUNT(go);
-                spins = 0;
-                if (flags_now & 1u) {
-                    flags_now = __builtin_amdgcn_readfirstlane(flags_now & ~1u);
-                    if (lane == 0) lds_post(c_status[1], flags_now | (ev_posted << 8));
-                }
-                // guard against rays that never end, as in render_kernel
-                rounds = __builtin_amdgcn_readfirstlane(rounds + 1u);
-                if ((rounds & 1023u) == 0u && rounds - progress_round >= (uint32_t)kMaxIter) {
-                    asm volatile("" ::: "memory");
-                    if (active && alive) {
-                        alive = false;
-                        if (p.status) atomicOr(p.status, 1u);
-                    }
-                    progress_round = rounds;
-                }
-                bool push = false;
-                uint32_t leaf = 0;
-                float weight = 0.f;
-                if (go) {
-                    float pos[3];
-                    pos[0] = P::madd(t, dir[0], cen[0]);
-                    pos[1] = P::madd(t, dir[1], cen[1]);
-                    pos[2] = P::madd(t, dir[2], cen[2]);
-                    int levels;
-                    uint32_t word;
-                    leaf = query_n2<false>(p, pos, &levels, &word, cur);
-                    const float dda = dda_unit<FMA>(pos, invdir);
-                    const float t_subcube = __builtin_amdgcn_ldexpf(dda, -levels);
-                    const float delta_t = t_subcube + p.step_size;
-                    const float sigma = h2f((uint16_t)(word & 0xFFFFu));
-                    bool stop = false;
-                    if (sigma > p.sigma_thresh) {  // rt_core.cuh:118-121,174
-                        const float att = vr_expf(-delta_t * delta_scale * sigma);
-                        weight = light * (1.f - att);
-                        push = true;
-                        light *= att;
-                        stop = light < p.stop_thresh;
-                    }
-                    if (stop) {
-                        stopped = true;
-                        alive = false;
-                    } else {
-                        t += delta_t;
-                        alive = t < tmax;
-                    }
-                }
-                const unsigned long long m_push = __builtin_amdgcn_ballot_w64(push);
-                TL2_ADD(tl2_query);
-                if (m_push != 0ull) {
-                    if (push) {
-                        const uint32_t seq =
-                            tail + __builtin_amdgcn_mbcnt_hi(
-                                       (uint32_t)(m_push >> 32),
-                                       __builtin_amdgcn_mbcnt_lo((uint32_t)m_push, 0u));
-                        const uint32_t j = seq & RM;
-                        it_leaf[j] = leaf;
-                        it_w[j] = weight;
-                        it_own[j] = (uint16_t)((uint32_t)lane | ((pushed & 7u) << 8));
-                        pushed += 1u;
-                    }
-                    tail = __builtin_amdgcn_readfirstlane(tail + (uint32_t)__builtin_popcountll(m_push));
-                    lds_fence();  // the entries are written before the tail moves past them
-                    if (lane == 0) lds_post(c_status[0], tail);
-                }
-                TL2_ADD(tl2_push);
-            }
-            if (aborted) running = false;
-        }
-        TL_DUMP_MARCH();
-        lds_fence();
-        if (lane == 0) lds_post(c_status[1], 2u | (ev_posted << 8));  // finished: everything this wave will ever post is visible
-    } else {
-        // =========================== shade wave ===========================
-        float* const res = reinterpret_cast<float*>(stage);  // 3 x 64 floats over the consumed rows
-        float mybasis[NB];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) mybasis[i] = 0.f;
-        float out[3] = {0.f, 0.f, 0.f};
-        uint32_t my_ray = 0;  // id of the ray whose colour this lane keeps
-        bool s_active = false;
-        uint32_t nseq = 0;  // items of this lane consumed so far
-        uint32_t head = 0, ev_done = 0;
-        TL_DECL_SHADE();
-
-        bool s_running = true;  // (one flat loop with a single exit, like the march wave's)
-        while (s_running) {
-            // ---- poll: ONE LDS read, scalar decisions; nothing else runs while there is nothing to
-            // do (a poll that already peeks at the ring costs ~15 vector instructions, and the
-            // shade waves spend a third of their time here: measured 48 % more VALU instructions
-            // than the fused kernel before this loop was cut down)
-            const unsigned long long st =
-                *(const __attribute__((address_space(3))) volatile unsigned long long*)&c_status[0];
-            const uint32_t tail = __builtin_amdgcn_readfirstlane((uint32_t)st);
-            const uint32_t fl = __builtin_amdgcn_readfirstlane((uint32_t)(st >> 32));
-            const uint32_t flags = fl & 3u;
-            const bool ev_pending = (fl >> 8) != (ev_done & 0xFFFFFFu);
-            asm volatile("" ::: "memory");  // ring entries are read after the tail that covers them
-            const uint32_t avail = tail - head;
-            const bool must_wait =
-                avail == 0u ||
-                (avail < (uint32_t)(VR_MS_MIN_CHUNK < ST::kShade ? VR_MS_MIN_CHUNK : ST::kShade) &&
-                 flags == 0u && !ev_pending);
-            // an event batch holds one ring position (published in ev_mask[2]); items in front of
-            // it are shaded first (a partial chunk), then the batch is handled
-            int n = avail < (uint32_t)ST::kShade ? (int)avail : ST::kShade;
-            uint32_t to_marker = 0xFFFFFFFFu;
-            if (ev_pending) to_marker = __builtin_amdgcn_readfirstlane(lds_peek(ev_mask[2])) - head;
-            if (to_marker < (uint32_t)n) n = (int)to_marker;
-            const uint32_t jmine = (head + (uint32_t)lane) & RM;
-            if (avail == 0u && (flags & 2u)) {
-                s_running = false;  // the march wave has finished and the ring is empty
-            } else if (must_wait) {
-                // nothing to do yet / the march wave is busy producing: wait for a full chunk
-                __builtin_amdgcn_s_sleep(VR_MS_SLEEP);
-                TL_ADD(tl_s_idle);
-            } else if (to_marker == 0u) {
-                // ---- event batch: finish pixels, take over the lanes' next rays ----
-                asm volatile("" ::: "memory");
-                const unsigned long long mask =
-                    (unsigned long long)ev_mask[0] | ((unsigned long long)ev_mask[1] << 32);
-                if ((mask >> lane) & 1ull) {
-                    const uint32_t w = ev_word[lane];
-                    const uint32_t r = w & 0x7FFFFFFFu;
-                    // one memory round trip for the whole batch: the finished ray's pixel address
-                    // (its words of the ray buffer; only the ray id is kept while it marches) and
-                    // the next ray's basis are requested together
-                    uint32_t px_lo = 0, px_hi = 0, fin_xy = 0, fin_frame = 0;
-                    if (s_active) {
-                        const uint32_t* rs = ray_slot(p.ray_buf, wpr, my_ray);
-                        px_lo = ray_word(rs, 13);
-                        px_hi = ray_word(rs, 14);
-                        if (p.any_accum) {
-                            fin_xy = ray_word(rs, 12);
-                            fin_frame = ray_word(rs, 15);
-                        }
-                    }
-                    // (the old ray's basis is dead: the new one loads straight into its registers)
-                    if (HAS_BASIS && r != kMsNoRay) {
-                        const uint32_t* rs = ray_slot(p.ray_buf, wpr, r);
-#pragma unroll
-                        for (int i = 0; i < NB; ++i) mybasis[i] = u2f(ray_word(rs, kRayWords + i));
-                    }
-                    if (s_active) {
-                        Ray ray;
-                        ray.out[0] = out[0];
-                        ray.out[1] = out[1];
-                        ray.out[2] = out[2];
-                        ray.out[3] = 0.f;
-                        ray.light = ev_light[lane];
-                        ray.stopped = (w >> 31) != 0u;
-                        ray.entered = true;
-                        RayCounters z;
-                        finish_ray<FMA, false>(
-                            p, ray, z,
-                            reinterpret_cast<uint8_t*>(((uint64_t)px_hi << 32) | (uint64_t)px_lo),
-                            fin_xy, (int)fin_frame);
-                    }
-                    s_active = r != kMsNoRay;
-                    my_ray = r;
-                    out[0] = out[1] = out[2] = 0.f;
-                }
-                head = __builtin_amdgcn_readfirstlane(head + 1u);
-                ev_done = __builtin_amdgcn_readfirstlane(ev_done + 1u);
-                lds_fence();  // the payload has been read before the march wave may overwrite it
-                if (lane == 0) {
-                    lds_post(c_head, head);
-                    lds_post(c_ev_done, ev_done);
-                }
-                TL_ADD(tl_s_event);
-            } else {
-            // ---- colour of n items, one per lane (shade_chunk of render_kernel) ----
-            // (the per-lane address terms below are loop invariants the compiler would rather keep
-            // in -- and then spill from -- registers than recompute: hide the lane id from it)
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            const bool have = lane < n;
-            const float weight = have ? it_w[jmine] : 0.f;
-            const uint32_t ownw = have ? (uint32_t)it_own[jmine] : (uint32_t)lane;
-            const int own4 = (int)(ownw & 63u) << 2;
-            auto basis_of = [&](int i) -> float {
-                return u2f((uint32_t)__builtin_amdgcn_ds_bpermute(own4, (int)f2u(mybasis[i])));
-            };
-            float bfull[ST::kPasses > 1 ? NB : 1];
-            if constexpr (ST::kPasses > 1) {
-#pragma unroll
-                for (int i = 0; i < NB; ++i) bfull[i] = basis_of(i);
-            }
-            auto basis_get = [&](int i) -> float {
-                if constexpr (ST::kPasses > 1) return bfull[i];
-                else return basis_of(i);
-            };
-            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-            if constexpr (!VR_EXP_SPLIT_COLOUR) {
-                r0 = r1 = r2 = weight;
-            } else if constexpr (ST::kEnabled) {
-#pragma unroll
-                for (int pass = 0; pass < ST::kPasses; ++pass) {
-                    if (pass * ST::kPass < n) {
-                        if (p.records_nt)
-                            issue_records<BASIS, true, kMsRing>(p, stage, it_leaf, head, ln, n, pass);
-                        else
-                            issue_records<BASIS, false, kMsRing>(p, stage, it_leaf, head, ln, n, pass);
-                        TL_ADD(tl_s_math);
-                        mem_fence();  // the DMAs have landed
-                        TL_ADD(tl_s_dma);
-                        if (ST::kPasses == 1 || ln / ST::kPass == pass) {
-                            const char* row = stage + (ln % ST::kPass) * ST::kRow;
-                            float acc[3];
-                            channel_sums<FMA, BASIS, (BASIS >= 16)>(row, basis_get, acc);
-                            if constexpr (VR_PACKED_EXP) {
-                                const float2v e01 = vr_expf2((float2v){-acc[0], -acc[1]}) + splat2(1.f);
-                                r0 = weight / e01.x;
-                                r1 = weight / e01.y;
-                            } else {
-                                r0 = weight / (1.f + vr_expf(-acc[0]));
-                                r1 = weight / (1.f + vr_expf(-acc[1]));
-                            }
-                            r2 = weight / (1.f + vr_expf(-acc[2]));
-                        }
-                        if (ST::kPasses > 1) lds_fence();  // rows are free for the next pass
-                    }
-                }
-            } else {
-                const float b0 = HAS_BASIS ? basis_of(0) : 0.f;
-                if (have) {
-                    Record<BASIS> rec;
-                    load_record<BASIS>(p, it_leaf[jmine], rec);
-                    if (HAS_BASIS) {
-                        r0 = weight / (1.f + vr_expf(-(b0 * rec.at(0))));
-                        r1 = weight / (1.f + vr_expf(-(b0 * rec.at(1))));
-                        r2 = weight / (1.f + vr_expf(-(b0 * rec.at(2))));
-                    } else {
-                        r0 = rec.at(0);
-                        r1 = rec.at(1);
-                        r2 = rec.at(2);
-                    }
-                }
-            }
-            lds_fence();  // every row has been read: `res` may overwrite them
-            if (have) {
-                res[0 * kWave + lane] = r0;
-                res[1 * kWave + lane] = r1;
-                res[2 * kWave + lane] = r2;
-                table[ownw & 63u][(ownw >> 8) & 7u] = (uint8_t)lane;
-            }
-            lds_fence();
-            // each owner adds the contributions of its own items in sequence order: its items of
-            // this chunk carry the sequence numbers nseq, nseq + 1, ... (at most kMsOutstanding)
-            const unsigned long long row8 = *reinterpret_cast<const unsigned long long*>(table[ln]);
-            uint32_t taken = 0;
-#pragma unroll 1
-            for (int d = 0; d < kMsOutstanding; ++d) {
-                const uint32_t e = (uint32_t)(row8 >> (((nseq + (uint32_t)d) & 7u) * 8u)) & 0xFFu;
-                const bool mine = e != 0xFFu;
-                if (!wave_any(mine)) break;
-                if (mine) {
-                    if (HAS_BASIS) {
-                        out[0] += res[0 * kWave + e];
-                        out[1] += res[1 * kWave + e];
-                        out[2] += res[2 * kWave + e];
-                    } else {
-                        const float w = it_w[(head + e) & RM];
-                        out[0] = P::madd(res[0 * kWave + e], w, out[0]);
-                        out[1] = P::madd(res[1 * kWave + e], w, out[1]);
-                        out[2] = P::madd(res[2 * kWave + e], w, out[2]);
-                    }
-                    taken += 1u;
-                }
-            }
-            if (taken) {
-                uint32_t ones = 0xFFFFFFFFu;
-                asm volatile("" : "+v"(ones));  // (a constant pair would be hoisted and spilled)
-                reinterpret_cast<uint32_t*>(table[ln])[0] = ones;
-                reinterpret_cast<uint32_t*>(table[ln])[1] = ones;
-                nseq += taken;
-                cons[ln] = (uint8_t)nseq;
-            }
-            head = __builtin_amdgcn_readfirstlane(head + (uint32_t)n);
-            lds_fence();
-            if (lane == 0) lds_post(c_head, head);
-            TL_ADD(tl_s_math);
-            TL_SHADE_CHUNK(n);
-            }
-        }
-        TL_DUMP_SHADE();
-    }
-}
-
-// ---------------------------------------------------------------------------
 // raygen_kernel: one lane per pixel of every frame of the launch, at full occupancy.
 // Ray generation, NDC warp, world->tree transform, view-direction rotation and the
 // ray/box test (volrend.cu:135-148, rt_core.cuh:74-92) with their FP64 islands,
@@ -2469,8 +1699,7 @@ __global__ void build_bricks_kernel(const uint32_t* nodes, const int32_t* brick_
 // grid = the persistent waves: as many as the chip holds of this flavour (or the tuning
 // override), but no more than about one wave per 128 rays of a small launch
 template <int FMA, int MODE>
-hipError_t launch_basis(const KParams& p, int64_t want, int n_cus, int waves_override, int split,
-                        hipStream_t s) {
+hipError_t launch_basis(const KParams& p, int64_t want, int n_cus, int waves_override, hipStream_t s) {
     const dim3 block(kWave);
     int b;
     if (p.basis_dim < 0 || p.format == VR_FORMAT_RGBA) {
@@ -2484,21 +1713,12 @@ hipError_t launch_basis(const KParams& p, int64_t want, int n_cus, int waves_ove
             default: b = BASIS_1; break;
         }
     }
-    // split != 0 (FAST flavours only): march and shade on separate waves, render_ms_kernel;
-    // a workgroup is a pair of waves, the grid counts pairs
 #define VR_LAUNCH(B)                                                                         \
     do {                                                                                     \
-        if (MODE == MODE_FAST && split) {                                                    \
-            const int64_t cap_ = (int64_t)n_cus * (waves_override > 0 ? (waves_override + 1) / 2 \
-                                                                      : ms_pairs_per_cu<B>()); \
-            const dim3 grid((unsigned)(want < cap_ ? want : cap_));                          \
-            hipLaunchKernelGGL((render_ms_kernel<FMA, B>), grid, dim3(2 * kWave), 0, s, p);  \
-        } else {                                                                             \
-            const int64_t cap_ = (int64_t)n_cus * (waves_override > 0 ? waves_override       \
+        const int64_t cap_ = (int64_t)n_cus * (waves_override > 0 ? waves_override           \
                                                                   : waves_per_cu<B, MODE>()); \
-            const dim3 grid((unsigned)(want < cap_ ? want : cap_));                          \
-            hipLaunchKernelGGL((render_kernel<FMA, B, MODE>), grid, block, 0, s, p);         \
-        }                                                                                    \
+        const dim3 grid((unsigned)(want < cap_ ? want : cap_));                              \
+        hipLaunchKernelGGL((render_kernel<FMA, B, MODE>), grid, block, 0, s, p);             \
     } while (0)
     switch (b) {
         case BASIS_RGBA: VR_LAUNCH(BASIS_RGBA); break;
@@ -2513,14 +1733,13 @@ hipError_t launch_basis(const KParams& p, int64_t want, int n_cus, int waves_ove
 }
 
 template <int FMA>
-hipError_t launch_fp(const KParams& p, int64_t want, int n_cus, int waves_override, int split,
-                     hipStream_t s) {
+hipError_t launch_fp(const KParams& p, int64_t want, int n_cus, int waves_override, hipStream_t s) {
     const bool n2 = (p.N == 2) && p.top_levels > 0;  // built at upload when the tree qualifies
     const bool lobes = p.format == VR_FORMAT_SG || p.format == VR_FORMAT_ASG;
-    if (!n2) return launch_basis<FMA, MODE_GENERIC>(p, want, n_cus, waves_override, 0, s);
+    if (!n2) return launch_basis<FMA, MODE_GENERIC>(p, want, n_cus, waves_override, s);
     if (lobes || p.instrumented || p.render_depth)  // the depth visualisation lives outside FAST
-        return launch_basis<FMA, MODE_FULL>(p, want, n_cus, waves_override, 0, s);
-    return launch_basis<FMA, MODE_FAST>(p, want, n_cus, waves_override, split, s);
+        return launch_basis<FMA, MODE_FULL>(p, want, n_cus, waves_override, s);
+    return launch_basis<FMA, MODE_FAST>(p, want, n_cus, waves_override, s);
 }
 
 }  // namespace
@@ -2531,7 +1750,7 @@ hipError_t launch_prepare(const KParams& p, const FrameTable& tbl, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_override, int split,
+hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_override,
                          hipStream_t stream) {
     if (p.n_wave_blocks <= 0 || p.n_frames <= 0) return hipSuccess;
     const int64_t total_blocks = p.n_wave_blocks * p.n_frames;
@@ -2554,8 +1773,8 @@ hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_ove
     if (want < 256) want = 256;
     if (want > total_blocks) want = total_blocks;
     const hipError_t e = fp_mode == VR_FP_FMA
-                             ? launch_fp<1>(p, want, n_cus, waves_override, split, stream)
-                             : launch_fp<0>(p, want, n_cus, waves_override, split, stream);
+                             ? launch_fp<1>(p, want, n_cus, waves_override, stream)
+                             : launch_fp<0>(p, want, n_cus, waves_override, stream);
     if (e != hipSuccess || !p.enable_probe || p.probe_disp_size <= 0) return e;
     const int side = p.probe_disp_size + 5;
     const dim3 pgrid((unsigned)((side * side + 255) / 256), (unsigned)p.n_frames);
@@ -2645,22 +1864,6 @@ hipError_t launch_decode_quant(const uint16_t* colors, const uint16_t* map, cons
 
 }  // namespace vr
 
-#if VR_TIMELINE == 3
-// experiment builds only (see the hooks at the top of this file): out = [kTl3Rows][kTl3Buckets] sums
-extern "C" int vr_exp_tl3_read(unsigned long long* out, int reset) {
-    using namespace vr;
-    static unsigned long long host[kTl3Copies][kTl3Rows][kTl3Buckets];
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(vr_tl3), sizeof(host)) != hipSuccess) return -1;
-    for (int r = 0; r < kTl3Rows; ++r)
-        for (int b = 0; b < kTl3Buckets; ++b) {
-            unsigned long long v = 0;
-            for (int c = 0; c < kTl3Copies; ++c) v += host[c][r][b];
-            out[r * kTl3Buckets + b] = v;
-        }
-    if (reset) {
-        for (auto& c : host) for (auto& r : c) for (auto& v : r) v = 0;
-        if (hipMemcpyToSymbol(HIP_SYMBOL(vr_tl3), host, sizeof(host)) != hipSuccess) return -1;
-    }
-    return kTl3Buckets;
-}
-#endif
+#define VR_HOOKS_PART 2
+#include "vr_experiment_hooks.h"
+#undef VR_HOOKS_PART
