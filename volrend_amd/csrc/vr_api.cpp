@@ -525,8 +525,16 @@ int basis_words_of(const VrTreeOpaque* t) {
     return (bd == 4 || bd == 9 || bd == 16 || bd == 25) ? bd : 1;
 }
 
-size_t ray_buffer_bytes(uint32_t total_rays, int basis_words) {
-    return (size_t)total_rays * (16 + (size_t)basis_words) * sizeof(uint32_t);  // kRayWords + basis
+// SH trees with a basis size the kernel knows: the ray record carries the view direction (3 words)
+// and the lane that takes the ray evaluates the basis; everything else carries the basis values
+bool ray_carries_vdir(const VrTreeOpaque* t) {
+    const int bw = basis_words_of(t);
+    return VR_RAY_VDIR && t->desc.format == VR_FORMAT_SH && bw > 3;
+}
+int ray_tail_words_of(const VrTreeOpaque* t) { return ray_carries_vdir(t) ? 3 : basis_words_of(t); }
+
+size_t ray_buffer_bytes(uint32_t total_rays, int tail_words) {
+    return (size_t)total_rays * (16 + (size_t)tail_words) * sizeof(uint32_t);  // kRayWords + tail
 }
 
 void fill_tree_params(vr::KParams& k, const VrTreeOpaque* t) {
@@ -1308,7 +1316,7 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.frame_group = tn.frame_group < 1 || tn.frame_group > n_frames ? n_frames : tn.frame_group;
     k.super_block = tn.super_block;
     // launch slot: per-launch scratch in device memory (ring, see LaunchSlot)
-    const size_t need = ray_buffer_bytes(k.total_rays, basis_words_of(t));
+    const size_t need = ray_buffer_bytes(k.total_rays, ray_tail_words_of(t));
     unsigned slot = kLaunchSlots;
     for (int want_fit = 1; want_fit >= 0 && slot == kLaunchSlots; --want_fit) {
         for (int pass = 0; pass < 2 && slot == kLaunchSlots; ++pass)
@@ -1339,6 +1347,8 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.chunk_max = tn.chunk_max;
     k.ray_count = k.ray_count_rw;
     k.basis_words = basis_words_of(t);
+    k.ray_tail_words = ray_tail_words_of(t);
+    k.ray_vdir = ray_carries_vdir(t) ? 1 : 0;
     if (ls.ray_bytes < need) {
         // First use of the slot, or a larger batch than any before: (re)allocate.  This is the
         // one place where an enqueue-only call may block -- on THIS slot's previous launch
@@ -1434,7 +1444,7 @@ int vr_reserve_tiles(vr_tree_t t, int width, int height, int n_frames, int tile_
     if (total >= (1ll << 30))
         return fail(VR_ERR_INVALID_ARGUMENT, "batch of %lld rays exceeds the 2^30-ray queue",
                     (long long)total);
-    const size_t need = ray_buffer_bytes((uint32_t)total, basis_words_of(t));
+    const size_t need = ray_buffer_bytes((uint32_t)total, ray_tail_words_of(t));
     DeviceGuard device_guard(t->device);
     std::lock_guard<std::mutex> guard(t->launch_mutex);
     for (int i = 0; i < n_slots; ++i) {

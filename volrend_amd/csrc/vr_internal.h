@@ -10,6 +10,9 @@ namespace vr {
 
 constexpr int kMaxBatch = 512;   // frames per launch (VR_MAX_BATCH)
 constexpr int kTableChunk = 48;  // frames per prepare_launch_kernel call (4 KB kernarg limit)
+#ifndef VR_RAY_VDIR
+#define VR_RAY_VDIR 1            // ray records of SH trees carry the view direction instead of the basis values
+#endif
 
 // Per-frame part of a launch: pose and buffers.  Lives in device memory (one
 // small table per launch slot) because lanes of one wave may hold rays of
@@ -88,7 +91,11 @@ struct KParams {
     uint32_t* ray_buf_rw;
     const uint32_t* ray_count;   // number of rays in ray_buf
     uint32_t* ray_count_rw;
-    int32_t basis_words;         // basis_fn words per ray in ray_buf (0 for RGBA)
+    int32_t basis_words;         // basis_fn values a ray carries in registers (0 for RGBA)
+    int32_t ray_tail_words;      // words of a ray record behind its 16-word head: the 3 words of the
+                                 // view direction (ray_vdir) or the basis_words basis values
+    int32_t ray_vdir;            // SH trees: the record carries the view direction, the basis is
+                                 // evaluated when a lane takes the ray
     int32_t refill_min;          // refill once this many lanes are idle
     int32_t march_max;           // march steps per lane between two shade checks
     int32_t flush_wait;          // shade a partial round once this many ended rays wait for colour (0 = never)

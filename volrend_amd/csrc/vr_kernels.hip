@@ -65,10 +65,11 @@ struct RayCounters {
 // ---------------------------------------------------------------------------
 // LOBES=false compiles the SH branch only (the hot configuration keeps zero
 // scratch); LOBES=true adds the SG / ASG lobes read from tree.extra.
-template <int FMA, bool LOBES>
+// BD > 0: the basis size is known at compile time (the render kernel's refill: SH only).
+template <int FMA, bool LOBES, int BD = 0>
 __device__ __forceinline__ void precalc_basis(const KParams& p, const float* dir, float* out) {
     using P = Policy<FMA>;
-    const int basis_dim = p.basis_dim;
+    const int basis_dim = BD > 0 ? BD : p.basis_dim;
     // NB: every index into out[] is a compile-time constant (loops fully
     // unrolled, predicated on basis_dim) so the array stays in VGPRs.
     if (LOBES && p.format == VR_FORMAT_ASG) {  // lumisphere.hpp:14-29
@@ -91,7 +92,7 @@ __device__ __forceinline__ void precalc_basis(const KParams& p, const float* dir
                 out[i] = vr_expf(ptr[0] * (dot3<FMA>(dir, ptr + 1) - 1.f)) / (float)basis_dim;
             }
         }
-    } else if (p.format == VR_FORMAT_SH) {  // lumisphere.hpp:38-81
+    } else if (BD > 0 || p.format == VR_FORMAT_SH) {  // lumisphere.hpp:38-81
         out[0] = (float)0.28209479177387814;
         const float x = dir[0], y = dir[1], z = dir[2];
         const float xx = x * x, yy = y * y, zz = z * z;
@@ -964,7 +965,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     uint32_t chunk_next = 0, chunk_end = 0;  // this wave's private range of ray ids
     uint32_t ring_head = 0, ring_tail = 0;  // items [head, tail) are waiting for a shader lane
     const uint32_t total = *p.ray_count;  // rays that entered the volume (raygen_kernel)
-    const int wpr = kRayWords + p.basis_words;  // words per ray in the ray buffer
+    const int wpr = kRayWords + p.ray_tail_words;  // words per ray in the ray buffer
     // scheduling statistics (instrumented flavours only): rounds and busy lanes per phase
     uint32_t st_march_r = 0, st_march_l = 0, st_shade_r = 0, st_shade_l = 0, st_distinct = 0,
              st_fin_r = 0, st_fin_l = 0, st_iter = 0;
@@ -1178,9 +1179,22 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     ray.delta_scale = u2f(ray_word(rs, 11));
                     ray_id = r;
                     if (HAS_BASIS && VR_EXP_FUSED_COLOUR) {
+                        if (BASIS > 1 && p.ray_vdir) {
+                            // rt_core.cuh:96-103: the basis of the ray's view direction (SH:
+                            // lumisphere.hpp:38-81), zeroed outside basis_minmax -- evaluated
+                            // here, by the lane that takes the ray, from 3 words of the record
+                            float vd[3];
 #pragma unroll
-                        for (int i = 0; i < NB; ++i)
-                            mybasis[i] = u2f(ray_word(rs, kRayWords + i));
+                            for (int i = 0; i < 3; ++i) vd[i] = u2f(ray_word(rs, kRayWords + i));
+                            precalc_basis<FMA, false, (BASIS > 1 ? BASIS : 1)>(p, vd, mybasis);
+#pragma unroll
+                            for (int i = 0; i < NB; ++i)
+                                if (i < p.basis_min || i > p.basis_max) mybasis[i] = 0.f;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < NB; ++i)
+                                mybasis[i] = u2f(ray_word(rs, kRayWords + i));
+                        }
                     }
                 }
             }
@@ -1404,7 +1418,7 @@ __global__ __launch_bounds__(kWave* kGenWaves) void raygen_kernel(const KParams 
     const uint32_t slot =
         wave_base[wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_valid >> 32),
                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)m_valid, 0u));
-    uint32_t* rb = ray_slot(p.ray_buf_rw, kRayWords + p.basis_words, slot);
+    uint32_t* rb = ray_slot(p.ray_buf_rw, kRayWords + p.ray_tail_words, slot);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         rb[(0 + i) * 64] = f2u(nr.cen[i]);
@@ -1418,7 +1432,13 @@ __global__ __launch_bounds__(kWave* kGenWaves) void raygen_kernel(const KParams 
     rb[13 * 64] = (uint32_t)reinterpret_cast<uint64_t>(px);
     rb[14 * 64] = (uint32_t)(reinterpret_cast<uint64_t>(px) >> 32);
     rb[15 * 64] = (uint32_t)frame;
-    if (p.basis_words > 0) {
+    if (p.ray_vdir) {
+        // SH trees: the (rotated) view direction travels, its basis is evaluated when a lane takes
+        // the ray (3 words instead of up to 25: the ray buffer is written and read once per ray)
+        rb[(kRayWords + 0) * 64] = f2u(vdir[0]);
+        rb[(kRayWords + 1) * 64] = f2u(vdir[1]);
+        rb[(kRayWords + 2) * 64] = f2u(vdir[2]);
+    } else if (p.basis_words > 0) {
         // rt_core.cuh:96-103: basis of the view direction, zeroed outside basis_minmax
         float b[VR_MAX_BASIS];
 #pragma unroll
