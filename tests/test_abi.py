@@ -91,7 +91,7 @@ def test_host_only_entry_points(lib_path):
     assert b"multiples of 8" in L.vr_last_error()
     assert L.vr_set_tuning(b"no_such_knob", 1) != 0
     assert L.vr_set_tuning(b"march_max", 2) == 0
-    assert L.vr_set_tuning(b"march_max", 16) == 0   # (the default again: trees uploaded later copy it)
+    assert L.vr_set_tuning(b"march_max", 12) == 0   # (the default again: trees uploaded later copy it)
     assert L.vr_tree_set_tuning(None, b"march_max", 2) != 0 and b"NULL" in L.vr_last_error()
     assert L.vr_reserve_tiles(None, 800, 800, 1, 0, 0, 1, 2) != 0
     # argument validation happens before any device call

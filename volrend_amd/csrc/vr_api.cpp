@@ -36,8 +36,8 @@ int fail(int code, const char* fmt, ...) {
 // the environment (VR_MARCH_MAX, VR_REFILL_MIN, VR_WAVES_PER_CU, ... read once) and
 // vr_set_tuning, which only affects trees uploaded afterwards and is serialised by a mutex.
 struct Tuning {
-    int march_max = 16;
-    int refill_min = 24;
+    int march_max = 12;
+    int refill_min = 20;
     int flush_wait = 0;    // partial shade round once this many ended rays wait for colour (0 = off)
     int waves_per_cu = 0;   // 0: what the kernel flavour fits (vr_kernels.hip waves_per_cu<>)
     int frame_group = 0;   // poses per ray-order group (0 = all poses of the launch, 1 = frame-major)
