@@ -736,12 +736,32 @@ static int upload_body(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     // helper thread while this one walks the tree on the host (topology check, node numbering):
     // the walks only read the child array, and hide completely behind the copies.
     // (a malformed tree is reported as such even where no device exists: no HIP error before that)
-    // The first HIP call of a process starts the runtime (~40 ms; 130-150 ms now and then, right
+    // The first HIP call of a process starts the runtime (~50 ms; 145-200 ms now and then, right
     // after another process released gigabytes of device memory -- the outlier of
-    // tools/upload_bench.py): it runs on the copier thread, beside the topology check, unless the
-    // input already lives on the device (then the runtime is up: the child array was just read).
+    // tools/upload_bench.py).  It has to be made on THIS thread (the tree goes to the caller's
+    // current device, and a new thread's current device is 0), so the topology check starts first,
+    // on a thread of its own, and runs beside it.
+    char why[256] = "";
+    std::vector<uint8_t> level;
+    int max_depth = -1;
+    bool walk_threw = false;
+    std::thread walker([&] {
+        try {
+            max_depth = validate_topology(host_child, d->capacity, N3, level, why, sizeof(why));
+        } catch (...) {
+            walk_threw = true;
+        }
+        if (timing) fprintf(stderr, "[volrend_hip] upload: topology checked at %.1f ms\n", since());
+    });
+    struct WalkerJoin {
+        std::thread& th;
+        ~WalkerJoin() {
+            if (th.joinable()) th.join();
+        }
+    } walker_join{walker};
     int device = 0;
-    hipError_t e_dev = d->memory == 1 ? hipGetDevice(&device) : hipSuccess;
+    const hipError_t e_dev = hipGetDevice(&device);
+    if (timing) fprintf(stderr, "[volrend_hip] upload: HIP runtime up at %.1f ms\n", since());
     int32_t* d_child = nullptr;
     uint16_t* d_data = nullptr;
     hipError_t e_copy = e_dev;
@@ -761,11 +781,6 @@ static int upload_body(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
         }
     } prefault_join{prefaulter};
     std::thread copier([&] {
-        if (d->memory != 1) {
-            e_dev = hipGetDevice(&device);
-            e_copy = e_dev;
-            if (timing) fprintf(stderr, "[volrend_hip] upload: HIP runtime up at %.1f ms\n", since());
-        }
         if (e_dev != hipSuccess) return;
         hipError_t e = hipSetDevice(device);
         // runtime start-up, the allocations and the copy pipeline's pinned slots + stream first:
@@ -808,18 +823,15 @@ static int upload_body(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
         }
     } joiner{copier, d_child, d_data, topo};
 
-    char why[256];
-    std::vector<uint8_t> level;
-    int max_depth = -1;
-    try {
-        max_depth = validate_topology(host_child, d->capacity, N3, level, why, sizeof(why));
-    } catch (...) {  // (the copier must be released before the exception travels on)
+    walker.join();
+    if (walk_threw) {  // (the copier must be released before the exception travels on)
         topo.store(-1, std::memory_order_release);
-        throw;
+        throw std::bad_alloc();
     }
     topo.store(max_depth < 0 ? -1 : 1, std::memory_order_release);
-    if (timing) fprintf(stderr, "[volrend_hip] upload: topology checked at %.1f ms\n", since());
     if (max_depth < 0) return fail(VR_ERR_BAD_TREE, "bad tree: %s", why);
+    if (e_dev != hipSuccess)
+        return fail(VR_ERR_HIP, "hipGetDevice failed: %s", hipGetErrorString(e_dev));
     // Lookup structure (N == 2 fast path): leaves must sit within 24 levels (exact integer
     // digits of a binary32 coordinate) and node*8+slot byte offsets must fit 32 bits.
     int G0 = 0, BL = 0;
@@ -847,6 +859,7 @@ static int upload_body(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     t->desc.data = nullptr;
     t->desc.extra = nullptr;
     t->max_depth = max_depth;
+    t->device = device;
     t->tn = tn;
     // new node numbering (host walk) while the copies are still in flight
     std::vector<int32_t> brick_roots;
@@ -856,11 +869,6 @@ static int upload_body(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     // re-layout into nodes/leaves, build the lookup structure, drop the staging copies
     if (timing) fprintf(stderr, "[volrend_hip] upload: host walks done at %.1f ms\n", since());
     copier.join();
-    if (e_dev != hipSuccess) {  // (`device` and e_dev belong to the copier until here)
-        delete t;
-        return fail(VR_ERR_HIP, "hipGetDevice failed: %s", hipGetErrorString(e_dev));
-    }
-    t->device = device;
     hipError_t e = e_copy;
     const int32_t* src_child = d->memory != 1 ? d_child : d->child;
     const uint16_t* src_data = (q || d->memory != 1) ? d_data : d->data;
