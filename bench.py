@@ -161,6 +161,37 @@ def committed_traffic(config: str, fp: str, profiles_dir: str | None = None, hav
 committed_traffic.last_profile = None
 
 
+def live_traffic(config: str, fp: str, frames_per_launch: int, tune: str):
+    """L2<->fabric bytes per frame of the render kernel at THIS launch shape, measured now: two
+    rocprofv3 --pmc passes (read-request sizes, WRITE_SIZE) of a child bench process
+    (tools/measure_traffic.py).  None where rocprofv3 is missing; {"error": ...} when it fails."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    out = tempfile.NamedTemporaryFile(suffix=".json", delete=False).name
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "measure_traffic.py"), "--config", config,
+           "--fp", fp, "--batch", str(frames_per_launch), "--groups", "rdsize", "write", "--out", out,
+           "--timeout", "150"]
+    if tune:
+        cmd += ["--bench-args", f"--tune {tune}"]
+    try:
+        p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=330)
+        d = json.load(open(out))
+        if "read_bytes_per_frame" not in d:
+            return {"error": "; ".join(d.get("failed_groups") or []) or p.stderr.decode(errors="replace")[-300:]}
+        return d
+    except Exception as e:  # noqa: BLE001 -- the committed measurement stays the fallback
+        return {"error": repr(e)}
+    finally:
+        try:
+            os.unlink(out)
+        except OSError:
+            pass
+
+
 def parity_check(stree, checks, width, height, focal, fp):
     """BASELINE's metric ends in "PSNR vs ref": frames the TIMED region produced (read back after
     it, nothing re-rendered) against the CPU oracle -- the checker, pinned bit for bit to the
@@ -240,6 +271,10 @@ def main():
                          "timed region finds the GPU in the power state of a running render loop "
                          "(after ~5 ms of idling an MI355X needs ~30 ms of work to be back at full "
                          "clocks: profiles/r04_lone_launch_probe.jsonl); 0 = none")
+    ap.add_argument("--live-traffic", type=int, default=-1,
+                    help="measure the L2<->fabric traffic of THIS run's launch shape with two rocprofv3 "
+                         "--pmc passes after the timed region (1), or report the committed, hash-verified "
+                         "measurement only (0); -1 = live when rocprofv3 is on the PATH, one GPU, config C1")
     ap.add_argument("--repeats", type=int, default=5,
                     help="after the timed region, the identical K-step region is run this many more "
                          "times (not part of value / ms_per_step): the line's own noise floor")
@@ -553,9 +588,26 @@ def main():
     # it still matches the sources this run was built from; otherwise null, and the reason.
     traffic, traffic_src, traffic_extrapolated = None, None, None
     launch_sizes = [min(B, K - j * B) for j in range(n_launch)]
+    live = None
+    want_live = args.live_traffic == 1 or (args.live_traffic < 0 and args.config == "C1")
+    if world == 1 and rank == 0 and want_live and not args.readback and n_streams == 1:
+        live = live_traffic(args.config, args.fp, launch_sizes[0], args.tune)
     if world == 1:
         per_frame, traffic_src, profiled_fpl = committed_traffic(args.config, args.fp,
                                                                  want_fpl=launch_sizes[0])
+        committed_note = traffic_src
+        if live is not None and "read_bytes_per_frame" in live:
+            # measured by THIS run, at this run's launch shape, on this box
+            per_frame = live["read_bytes_per_frame"] + live.get("write_bytes_per_frame", 0.0)
+            profiled_fpl = launch_sizes[0]
+            traffic_src = (f"measured by this run: two rocprofv3 --kernel-trace --pmc passes of the same "
+                           f"launch shape ({launch_sizes[0]} frames per launch) after the timed region "
+                           f"(tools/measure_traffic.py: TCC_EA0_RDREQ_128B*128 + _64B*64 + _32B*32 + "
+                           f"WRITE_SIZE; kernel under the profiler "
+                           f"{live['kernel_ms_under_pmc'].get('rdsize', 0):.3f} ms per launch); committed "
+                           f"profile: {committed_note}")
+        elif live is not None:
+            traffic_src = f"{traffic_src}; live measurement failed: {live.get('error', '?')[:160]}"
         if per_frame is not None:
             traffic = int(per_frame * K / n_launch)
             traffic_extrapolated = any(n != profiled_fpl for n in launch_sizes)

@@ -118,6 +118,7 @@ def main():
     kernel = f"render_kernel<{fpi}, {basis}, 0>"
     bench_args = ["--config", args.config, "--fp", args.fp, "--batch", str(args.batch), "--steps",
                   str(2 * args.batch), "--warmup", str(args.batch), "--no-cpu-baseline", "--no-parity",
+                  "--live-traffic", "0", "--repeats", "0", "--preroll", "0",
                   *args.bench_args.split()]
     tmp = tempfile.mkdtemp(prefix="vr_pmc_")
     c, durations, failed = {}, {}, []
