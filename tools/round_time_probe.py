@@ -60,7 +60,8 @@ def main():
                 mean_s.append(float(samples.mean()))
                 n_in.append(int((samples > 0).sum()))
         for tune in args.tunes.split(";"):
-            tree.set_tuning(**{k: int(x) for k, x in (kv.split("=") for kv in tune.split(","))})
+            if tune:
+                tree.set_tuning(**{k: int(x) for k, x in (kv.split("=") for kv in tune.split(","))})
             per_pose = []
             for tr in trs:
                 pb = api.PreparedBatch(tree, cam, [tr], api.RenderOptions(), [img], True)
