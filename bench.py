@@ -173,12 +173,12 @@ def live_traffic(config: str, fp: str, frames_per_launch: int, tune: str):
     out = tempfile.NamedTemporaryFile(suffix=".json", delete=False).name
     cmd = [sys.executable, os.path.join(ROOT, "tools", "measure_traffic.py"), "--config", config,
            "--fp", fp, "--batch", str(frames_per_launch), "--groups", "rdsize", "write", "--out", out,
-           "--timeout", "150"]
+           "--timeout", "60"]  # (a pass takes ~5 s; a profiler that hangs must not hold the bench up)
     if tune:
         cmd += ["--bench-args", f"--tune {tune}"]
     try:
         p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE, timeout=330)
+                           stderr=subprocess.PIPE, timeout=135)
         d = json.load(open(out))
         if "read_bytes_per_frame" not in d:
             return {"error": "; ".join(d.get("failed_groups") or []) or p.stderr.decode(errors="replace")[-300:]}
