@@ -588,7 +588,7 @@ def main():
     # it still matches the sources this run was built from; otherwise null, and the reason.
     traffic, traffic_src, traffic_extrapolated = None, None, None
     launch_sizes = [min(B, K - j * B) for j in range(n_launch)]
-    live = None
+    live, committed_note = None, None
     want_live = args.live_traffic == 1 or (args.live_traffic < 0 and args.config == "C1")
     if world == 1 and rank == 0 and want_live and not args.readback and n_streams == 1:
         live = live_traffic(args.config, args.fp, launch_sizes[0], args.tune)
@@ -709,7 +709,7 @@ def main():
             "shade_rounds_per_frame": int(sched["shade_rounds"] / n_distinct),
             "valu_insts_per_frame": prof.get("valu_insts_per_frame"),
             "salu_insts_per_frame": prof.get("salu_insts_per_frame"),
-            "valu_source": traffic_src if prof else "no hash-verified PMC profile of these sources",
+            "valu_source": committed_note if prof else "no hash-verified PMC profile of these sources",
         }
         if parity_frames:
             result["parity"] = parity_check(stree, parity_frames, W, H, focal, args.fp)
