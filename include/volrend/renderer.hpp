@@ -27,6 +27,8 @@
 
 namespace volrend {
 
+// The stream and the frames live on the device of the tree that is set (the calling thread's
+// current device while there is none): set() of a tree on another device moves them.
 struct VolumeRenderer {
     explicit VolumeRenderer();
     ~VolumeRenderer();
@@ -58,11 +60,14 @@ struct VolumeRenderer {
     // ---- in place of the GL framebuffer ----
     // Device images every render() starts from (both optional, camera.width x camera.height,
     // dense rows): what upstream's meshes leave in the colour and the R32F depth attachment.
-    // The buffers stay the caller's; they are copied on render()'s stream.
+    // The buffers stay the caller's; they are copied on render()'s stream.  They belong to the
+    // frame size of the moment: after resize() hand them in again (render() refuses a stale pair).
     void set_underlay(const void* rgba8_dev, const float* depth_dev);
     // The frame the last render() wrote (device memory, RGBA8, width * 4 bytes per row)
     const uint8_t* frame() const;
-    // Waits for the last render() and copies its frame to host memory (width * height * 4 bytes)
+    // Waits for the last render() and copies its frame to host memory (width * height * 4 bytes).
+    // Throws if a launch reported rays cut by the sample guard (check_render_status,
+    // volrend/renderer_kernel.hpp): a wrong frame is not handed out as a good one.
     void read_frame(void* host_rgba8);
     // The stream render() enqueues on (hipStream_t)
     void* stream() const;

@@ -25,4 +25,11 @@ void launch_renderer_batch(const N3Tree& tree, const Camera& cam,
                            const RenderOptions& options, const std::vector<void*>& images,
                            void* stream, bool offscreen = true);
 
+// launch_renderer only enqueues, so it cannot report what a launch found out on the device: the
+// sticky status word of the tree (vr_tree_status; bit 0 = rays hit the sample guard, their
+// pixels are wrong).  Call this once the stream is idle -- the end of a render loop, or after the
+// copy of a frame -- to get the reference's loud failure (src/cuda/common.cu:8-21 prints and
+// exits; this throws std::runtime_error and clears the word).  Synchronous.
+void check_render_status(const N3Tree& tree);
+
 }  // namespace volrend

@@ -242,13 +242,21 @@ int vr_reserve(vr_tree_t tree, int width, int height, int n_frames);
  * n_slots launch slots are sized (1..8: one per stream that renders this tree concurrently). */
 int vr_reserve_tiles(vr_tree_t tree, int width, int height, int n_frames, int tile_w, int tile_h,
                      int world, int n_slots);
-/* Sticky device status word of the tree's launches: bit 0 = some ray hit the 2^22-sample
- * guard (the reference would still be looping).  Synchronous; reset != 0 clears it.
+/* Sticky device status word of the tree's launches: bit 0 = some ray hit the sample guard (a
+ * wave marched 2^22 rounds -- tuning key "max_iter" -- without retiring a single ray; the
+ * reference would still be looping).  Synchronous; reset != 0 clears it.
  * vr_render* refuses step_size <= 0 / NaN (VR_ERR_INVALID_ARGUMENT), where the reference
- * hangs, so the bit only ever fires on pathological step_size / scene combinations. */
+ * hangs, so the bit only ever fires on pathological step_size / scene combinations.  A launch
+ * that set it has WRONG pixels (the wave's marching rays were cut; which rays share a wave
+ * depends on the scheduling knobs, so such a frame is not tuning-independent either): vr_render*
+ * is enqueue-only and cannot report it, so every render loop checks this word once its last
+ * launch has finished -- volrend_headless, TileShardRenderer::sync, VolumeRenderer::read_frame
+ * and bench.py do, and fail loudly (the reference's abort-on-error convention,
+ * src/cuda/common.cu:8-21). */
 int vr_tree_status(vr_tree_t tree, uint32_t* status, int reset);
 /* Scheduling / layout knobs ("march_max", "refill_min", "waves_per_cu", "records_nt",
- * "top_levels", "brick_levels", ...); results never depend on them.  Every tree carries its own
+ * "top_levels", "brick_levels", ...); results never depend on them ("max_iter", the sample
+ * guard above, is the exception by design: a launch that trips it says so in vr_tree_status).  Every tree carries its own
  * copy, taken at upload (or from the source of a clone) from the process defaults:
  *   vr_set_tuning       changes the DEFAULTS of trees uploaded afterwards (serialised);
  *   vr_tree_set_tuning  changes one tree (not the upload-time keys top_levels / brick_levels);

@@ -4,7 +4,7 @@
 // compositing path (offscreen = 0).
 //
 //   renderer_check <tree.npz> <spec.txt> <out.raw>
-// spec: "size W H FX FY", "background_brightness b", "underlay <rgba.raw> <depth.raw>" (optional),
+// spec: "size W H FX FY", "background_brightness b", "step_size s", "underlay <rgba.raw> <depth.raw>" (optional),
 //       one "cam cx cy cz bx by bz" per frame (camera centre and v_back; v_world_up stays +z).
 // stdout: one "transform f0 .. f11" line per frame (what Camera::_update made of the vectors)
 //         and "basis_minmax a b backend NAME".
@@ -40,6 +40,7 @@ int main(int argc, char* argv[]) {
             if (!(is >> key)) continue;
             if (key == "size") is >> w >> h >> r.camera.fx >> r.camera.fy;
             else if (key == "background_brightness") is >> r.options.background_brightness;
+            else if (key == "step_size") is >> r.options.step_size;
             else if (key == "underlay") is >> under_rgba >> under_depth;
             else if (key == "cam") {
                 std::vector<float> c(6);

@@ -173,7 +173,10 @@ int main(int argc, char* argv[]) {
     args.add("reverse_yz", 'r', true, "", "use OpenCV camera space convention instead of NeRF");
     args.add("scale", 0, false, "1.0", "scaling to apply to image");
     args.add("max_imgs", 0, false, "0", "max images to render, default no limit");
-    args.add("batch", 0, false, "32", "poses per launch (1..512)");
+    args.add("batch", 0, false, "32",
+             "poses per launch and GPU (1..512): a launch carries batch x max(1, --gpus) poses, at "
+             "most 512, and the pose list is cut into EQUAL launches (200 poses at 32: 7 launches "
+             "of 29 / 28 -- no short last launch)");
     args.add("gpus", 0, false, "0",
              "render every frame on this many GPUs (devices --gpu .. --gpu+N-1): interleaved "
              "screen tiles, tree replicated device to device, RCCL gather of the RGBA8 tiles to "
@@ -277,13 +280,21 @@ int main(int argc, char* argv[]) {
             basenames.resize(max_imgs);
         }
     }
+    const int n_gpus = args.as_int("gpus");
     int batch = args.as_int("batch");
     if (batch < 1) batch = 1;
+    // A launch pays one ray-chain latency of ramp-up + tail whatever it carries, and under
+    // --gpus N every rank only renders 1/N of each frame: the launch grows with N so that the
+    // work per rank and launch does not shrink (bench.py --gpus N does the same).
+    if (n_gpus > 1) batch *= n_gpus;
     if (batch > VR_MAX_BATCH) batch = VR_MAX_BATCH;
+    // equal launches: ceil(P / batch) of them, sizes differing by at most one pose
+    const size_t n_launches = (trans.size() + (size_t)batch - 1) / (size_t)batch;
+    batch = (int)((trans.size() + n_launches - 1) / n_launches);
+    const size_t n_long = trans.size() - (size_t)(batch - 1) * n_launches;  // launches of `batch` poses; the rest carry one less
     const int fp_mode = args.str("fp") == "fma" ? VR_FP_FMA : VR_FP_STRICT;
 
     const size_t frame_bytes = (size_t)width * height * 4;
-    const int n_gpus = args.as_int("gpus");
     const RenderOptions options = internal::render_options_from_args(args);
     VrRenderOptions copt;
     vr_default_options(&copt);
@@ -358,8 +369,8 @@ int main(int argc, char* argv[]) {
     int seq = 0;
     size_t prev_first = 0;
     int prev_n = 0;
-    for (size_t first = 0; first < trans.size(); first += batch, ++seq) {
-        const int n = (int)std::min<size_t>(batch, trans.size() - first);
+    for (size_t first = 0; first < trans.size(); ++seq) {
+        const int n = (size_t)seq < n_long ? batch : batch - 1;
         const int set = seq & 1;
         std::vector<VrCamera> cams((size_t)n);
         std::vector<VrFrame> frames((size_t)n);
@@ -408,6 +419,7 @@ int main(int argc, char* argv[]) {
             prev_first = first;
             prev_n = n;
         }
+        first += (size_t)n;
     }
     if (pool) {
         if (prev_n > 0) submit_encodes((seq - 1) & 1, prev_first, prev_n);
@@ -416,7 +428,16 @@ int main(int argc, char* argv[]) {
     }
     HIP_OK(hipEventRecord(stop, stream));
     HIP_OK(hipEventSynchronize(stop));
-    if (shard) shard->sync();
+    // Everything has run: what the launches found out on the device surfaces now -- a ray that
+    // hit the sample guard means wrong frames, and the reference's convention for device errors
+    // is message + non-zero exit (src/cuda/common.cu:8-21).
+    try {
+        if (shard) shard->sync();  // (checks the status word of every rank's tree)
+        else check_render_status(tree);
+    } catch (const std::exception& e) {
+        fprintf(stderr, "ERROR: %s\n", e.what());
+        return 1;
+    }
     float milliseconds = 0;
     HIP_OK(hipEventElapsedTime(&milliseconds, start, stop));
     milliseconds = milliseconds / trans.size();

@@ -16,6 +16,25 @@ void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess)
         throw std::runtime_error(std::string("VolumeRenderer: ") + what + ": " + hipGetErrorString(e));
 }
+// The renderer's stream and frames live on the device of the tree it renders (launch_renderer
+// runs there whatever the calling thread's current device is); the thread's device is restored.
+class OnDevice {
+   public:
+    explicit OnDevice(int device) {
+        if (device < 0) return;
+        if (hipGetDevice(&prev_) == hipSuccess && prev_ != device)
+            switched_ = hipSetDevice(device) == hipSuccess;
+    }
+    ~OnDevice() {
+        if (switched_) (void)hipSetDevice(prev_);
+    }
+    OnDevice(const OnDevice&) = delete;
+    OnDevice& operator=(const OnDevice&) = delete;
+
+   private:
+    int prev_ = 0;
+    bool switched_ = false;
+};
 }  // namespace
 
 struct VolumeRenderer::Impl {
@@ -29,9 +48,34 @@ struct VolumeRenderer::Impl {
     int width = 0, height = 0;  // size of the allocations
     const void* under_rgba = nullptr;
     const float* under_depth = nullptr;
+    int under_w = 0, under_h = 0;  // the size the underlay buffers were handed in for
+    int device = -1;               // where stream and frames live (-1: nothing created yet)
 
+    // The tree's device (the current one while no tree is set).  Moving to another device drops
+    // the stream and the frames: they are re-created there.
+    int target_device() const {
+        int d = 0;
+        if (tree && tree->device) {
+            VrTreeInfo info;
+            if (vr_tree_info(tree->device, &info) == VR_OK) return info.device;
+        }
+        (void)hipGetDevice(&d);
+        return d;
+    }
     void start() {  // cuda_renderer.cpp:59-81 without the GL objects
-        if (!stream) hip_check(hipStreamCreate(&stream), "hipStreamCreate");
+        const int want = target_device();
+        if (stream && device != want) {
+            OnDevice on(device);
+            (void)hipStreamSynchronize(stream);
+            release();
+            (void)hipStreamDestroy(stream);
+            stream = nullptr;
+        }
+        if (!stream) {
+            OnDevice on(want);
+            hip_check(hipStreamCreate(&stream), "hipStreamCreate");
+            device = want;
+        }
     }
     void release() {
         for (int i = 0; i < 2; ++i) {
@@ -56,6 +100,7 @@ struct VolumeRenderer::Impl {
         height = h;
     }
     ~Impl() {
+        OnDevice on(device);
         if (stream) (void)hipStreamSynchronize(stream);
         release();
         if (stream) (void)hipStreamDestroy(stream);
@@ -68,8 +113,14 @@ VolumeRenderer::~VolumeRenderer() = default;
 void VolumeRenderer::render() {
     Impl& m = *impl_;
     m.start();
+    OnDevice on(m.device);
     m.allocate(camera.width, camera.height);
     if (m.width <= 0) return;
+    if ((m.under_rgba || m.under_depth) && (m.under_w != m.width || m.under_h != m.height))
+        throw std::runtime_error("VolumeRenderer::render: the underlay was set for " +
+                                 std::to_string(m.under_w) + "x" + std::to_string(m.under_h) +
+                                 ", the frame is " + std::to_string(m.width) + "x" +
+                                 std::to_string(m.height) + " (set_underlay again after resize)");
     const size_t px = (size_t)m.width * m.height;
     uint8_t* frame = m.rgba[m.buf_index];
     float* depth = m.depth[m.buf_index];
@@ -103,10 +154,10 @@ void VolumeRenderer::render() {
 }
 
 void VolumeRenderer::set(N3Tree& tree) {  // cuda_renderer.cpp:171-180
-    impl_->start();
     if (!tree.is_cuda_loaded())
         throw std::runtime_error("VolumeRenderer::set: the tree is not on the device (N3Tree::open uploads it)");
     impl_->tree = &tree;
+    impl_->start();  // (moves the stream and the frames to the tree's device if need be)
     options.basis_minmax[0] = 0;
     options.basis_minmax[1] = std::max(tree.data_format.basis_dim - 1, 0);
 }
@@ -118,6 +169,7 @@ void VolumeRenderer::resize(int width, int height) {  // cuda_renderer.cpp:128-1
         impl_->height == height)
         return;
     impl_->start();
+    OnDevice on(impl_->device);
     camera.width = width;
     camera.height = height;
     impl_->allocate(width, height);
@@ -128,6 +180,8 @@ const char* VolumeRenderer::get_backend() { return "HIP"; }  // upstream: "CUDA"
 void VolumeRenderer::set_underlay(const void* rgba8_dev, const float* depth_dev) {
     impl_->under_rgba = rgba8_dev;
     impl_->under_depth = depth_dev;
+    impl_->under_w = camera.width;
+    impl_->under_h = camera.height;
 }
 
 const uint8_t* VolumeRenderer::frame() const {
@@ -137,9 +191,13 @@ const uint8_t* VolumeRenderer::frame() const {
 void VolumeRenderer::read_frame(void* host_rgba8) {
     Impl& m = *impl_;
     if (m.last < 0) throw std::runtime_error("VolumeRenderer::read_frame: nothing rendered yet");
+    OnDevice on(m.device);
     hip_check(hipMemcpyAsync(host_rgba8, m.rgba[m.last], (size_t)m.width * m.height * 4,
                              hipMemcpyDeviceToHost, m.stream), "hipMemcpyAsync(read_frame)");
     hip_check(hipStreamSynchronize(m.stream), "hipStreamSynchronize");
+    // the stream is idle: what the launches found out on the device (the sample guard) surfaces
+    // here, loudly, instead of a wrong frame handed out as a good one
+    if (m.tree) check_render_status(*m.tree);
 }
 
 void* VolumeRenderer::stream() const { return impl_->stream; }

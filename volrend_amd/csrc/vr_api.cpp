@@ -47,6 +47,8 @@ struct Tuning {
     int chunk_max = 4096;
     int top_levels = 0;    // lookup structure built at upload (vr_kernels.hip); 0 = auto
     int brick_levels = 3;
+    int max_iter = 1 << 22;  // the sample guard (vr_kernels.hip); the one knob that is NOT scheduling-only:
+                             // a launch that trips it reports through vr_tree_status (tests lower it)
 };
 std::mutex g_tuning_mutex;
 Tuning& default_tuning_locked() {  // call with g_tuning_mutex held
@@ -63,6 +65,7 @@ Tuning& default_tuning_locked() {  // call with g_tuning_mutex held
         if (const char* e = getenv("VR_CHUNK_MAX")) x.chunk_max = atoi(e) < 64 ? 64 : (atoi(e) & ~63);
         if (const char* e = getenv("VR_TOP_LEVELS")) x.top_levels = atoi(e);
         if (const char* e = getenv("VR_BRICK_LEVELS")) x.brick_levels = atoi(e);
+        if (const char* e = getenv("VR_MAX_ITER")) x.max_iter = atoi(e) < 1 ? 1 : atoi(e);
         return x;
     }();
     return tn;
@@ -83,6 +86,7 @@ bool set_tuning_key(Tuning& tn, const char* key, int value) {
     else if (!strcmp(key, "chunk_max")) tn.chunk_max = value < 64 ? 64 : (value & ~63);
     else if (!strcmp(key, "top_levels")) tn.top_levels = value;
     else if (!strcmp(key, "brick_levels")) tn.brick_levels = value;
+    else if (!strcmp(key, "max_iter")) tn.max_iter = value < 1 ? 1 : value;
     else return false;
     return true;
 }
@@ -1332,6 +1336,7 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     k.march_max = tn.march_max;
     k.refill_min = tn.refill_min;
     k.flush_wait = tn.flush_wait;
+    k.max_iter = tn.max_iter;
     k.frame_group = tn.frame_group < 1 || tn.frame_group > n_frames ? n_frames : tn.frame_group;
     k.super_block = tn.super_block;
     // launch slot: per-launch scratch in device memory (ring, see LaunchSlot)

@@ -22,6 +22,8 @@
 #define VR_EXP_RECORD_DMA 1                        // record DMAs are issued
 #define VR_EXP_FUSED_COLOUR 1                      // hit samples queue colour work
 #define VR_EXP_STEAL 1                             // waves steal from the ray queues of other XCDs
+#define VR_EXP_TOP_ENTRY(load) (load)              // the top-grid entry of a cell
+#define VR_EXP_BRICK_WORD(load) (load)             // the brick entry of a sample
 #else
 #define VR_EXP_RECORD_CHUNK(v, j, leaf) \
     (VR_ABLATE == 1 ? (v)[0] : VR_ABLATE == 2 ? make_uint4((leaf) + (j), (leaf), (leaf), (leaf)) : (v)[j])
@@ -29,6 +31,11 @@
 #define VR_EXP_RECORD_DMA (VR_ABLATE != 4)         // 4: no record fetch at all
 #define VR_EXP_FUSED_COLOUR (VR_ABLATE != 6)       // 6: the kernel marches without colour work
 #define VR_EXP_STEAL (VR_ABLATE != 8)              // 8: every wave stays with the ray queue of its XCD (same pictures)
+// 9 / 10: the march without its memory latency -- every sample "finds" an empty leaf of depth G0 + 3
+// without a brick load (9) and without the top load either (10): rays cross the whole volume in
+// finest-level steps, nothing is shaded; what a round costs then is its instruction chain alone
+#define VR_EXP_BRICK_WORD(load) (VR_ABLATE == 9 || VR_ABLATE == 10 ? (kLeafBit | (2u << 29)) : (load))
+#define VR_EXP_TOP_ENTRY(load) (VR_ABLATE == 10 ? make_uint2(0u, 0u) : (load))
 #endif
 #if VR_TIMELINE == 1
 #define TL_MARK() (tl_mark = __builtin_readcyclecounter())

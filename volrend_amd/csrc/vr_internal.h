@@ -99,6 +99,7 @@ struct KParams {
     int32_t refill_min;          // refill once this many lanes are idle
     int32_t march_max;           // march steps per lane between two shade checks
     int32_t flush_wait;          // shade a partial round once this many ended rays wait for colour (0 = never)
+    int32_t max_iter;            // guard: march rounds of a wave without a retired ray before it cuts its rays
     int32_t instrumented;        // any frame carries counters -> FULL flavour
     int32_t any_accum;           // some frame of the launch asks for its fp32 accumulators
     int32_t records_nt;          // record DMA loads carry the non-temporal hint (large lookup structures)

@@ -46,7 +46,8 @@ constexpr int kWave = 64;
 #ifndef VR_PACKED_EXP
 #define VR_PACKED_EXP 1       // the sigmoids of channels 0/1 share packed mul / fma / add instructions
 #endif
-constexpr int kMaxIter = 1 << 22;  // guard against step_size <= 0 (upstream would spin forever)
+// Guard against rays that never end (upstream would spin forever): KParams.max_iter march rounds
+// of a wave without a single retired ray, default 2^22 (tuning key `max_iter`, for tests).
 
 enum { BASIS_RGBA = -1, BASIS_1 = 1, BASIS_4 = 4, BASIS_9 = 9, BASIS_16 = 16, BASIS_25 = 25 };
 
@@ -252,8 +253,8 @@ __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* 
     const uint32_t cell = ((((ux >> sh0) << g0) | (uy >> sh0)) << g0) | (uz >> sh0);
     if (cell != cur.cell) {
         // 32-bit byte offsets from a uniform base (top: <= 128 MB; bricks: < 4 GB, upload)
-        const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.top) +
-                                                        (cell << 3));
+        const uint2 e = VR_EXP_TOP_ENTRY(*reinterpret_cast<const uint2*>(
+            reinterpret_cast<const char*>(p.top) + (cell << 3)));
         if (COUNT) touch(p, TOUCH_TOP, (uint64_t)cell * 8u, 8u);
         cur.cell = cell;
         cur.e0 = e.x;
@@ -270,7 +271,8 @@ __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* 
                              __builtin_amdgcn_ubfe(uz, sh1, bl);
         const uint32_t entry = (w << (3u * bl)) + sub;
         if (COUNT) touch(p, TOUCH_BRICKS, (uint64_t)entry * 4u, 4u);
-        w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.bricks) + (entry << 2));
+        w = VR_EXP_BRICK_WORD(*reinterpret_cast<const uint32_t*>(
+            reinterpret_cast<const char*>(p.bricks) + (entry << 2)));
         if (w & kLeafBit) {
             d = (int)(g0 + 1u + __builtin_amdgcn_ubfe(w, 29u, 2u));
             id = (id << 3) + __builtin_amdgcn_ubfe(w, 16u, 13u);  // (root + delta) * 8 + slot
@@ -1138,7 +1140,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
             }
             const bool vacant = done || !ray.active;
             bool take = false;
-            progress_round = rounds;
+            if (m_done != 0ull) progress_round = rounds;  // (a ray retired: the wave makes progress)
             // Idle lanes take consecutive rays from the buffer.  The wave owns a private
             // chunk [chunk_next, chunk_end) of ray ids and only goes to the global queue
             // head (ONE returning atomic -- a single word sustains ~90 of them per
@@ -1225,11 +1227,13 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         // ---- march: lanes with a live ray and room for another outstanding item ----
         TL_ADD(tl_refill);
         // Guard against rays that never end (not in the reference, which would spin): when the
-        // wave has marched kMaxIter rounds without retiring a single ray, whatever is still
-        // marching is cut and reported.  Wave-uniform and checked once per pass through here
+        // wave has marched p.max_iter rounds without retiring a single ray, whatever is still
+        // marching is cut and reported (sticky status bit 0: the host layers fail loudly on it;
+        // WHICH rays share a wave depends on the scheduling knobs, so the pixels of a launch that
+        // tripped the guard are not tuning-independent -- they are wrong either way).  Wave-uniform and checked once per pass through here
         // (<= march_max rounds), so that a march round carries nothing of it (five vector and
         // four scalar instructions per round until round 3; -2 % frame time, profiles/r04_*).
-        if (rounds - progress_round >= (uint32_t)kMaxIter) {
+        if (rounds - progress_round >= (uint32_t)p.max_iter) {
             if (ray.t < ray.tmax) {
                 ray.t = ray.tmax;
                 if (p.status) atomicOr(p.status, 1u);
