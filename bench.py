@@ -34,6 +34,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# The kernel's own lower bounds (roofline.model), each from a measurement on this chip:
+GATHER_LINES_PER_S = 53.5e9   # random 128-byte line requests the chip retires per second whatever the
+                              # record size (tools/gather_bench.hip, profiles/r01_gather_ceiling.txt)
+N_SIMD, SIMD_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, peak shader clock (MI355X_MICROARCH.md)
+VALU_ISSUE_CYCLES = 4.0       # a wave64 vector instruction of this kernel's mix occupies its SIMD for 2.5-4
+                              # cycles (profiles/r04_valu_issue_cost.jsonl); 4 = the price SQ_ACTIVE_INST_VALU counts
+ROUND_FLOOR_US = 0.62         # a dependent march round of a lone wave on an otherwise idle SIMD: 1300-1500
+                              # shader clocks (profiles/r04_tail_profile.jsonl, the last buckets of a one-frame launch)
 CACHE_DIR = os.environ.get("VOLREND_BENCH_CACHE", "/dev/shm/volrend_amd_cache")
 
 
@@ -140,7 +148,8 @@ def committed_traffic(config: str, fp: str, profiles_dir: str | None = None, hav
     reason = f"no profiles/r*_traffic_{config}.json"
     found = []
     for tpath in sorted(glob.glob(os.path.join(profiles_dir, f"r*_traffic_{config}*.json")), reverse=True):
-        tj = json.load(open(tpath))
+        with open(tpath) as f:
+            tj = json.load(f)
         rel = os.path.join("profiles", os.path.basename(tpath))
         if tj.get("config") != config or tj.get("fp_mode") != fp or "read_bytes_per_frame" not in tj:
             continue
@@ -173,13 +182,14 @@ def live_traffic(config: str, fp: str, frames_per_launch: int, tune: str):
     out = tempfile.NamedTemporaryFile(suffix=".json", delete=False).name
     cmd = [sys.executable, os.path.join(ROOT, "tools", "measure_traffic.py"), "--config", config,
            "--fp", fp, "--batch", str(frames_per_launch), "--groups", "rdsize", "write", "--out", out,
-           "--timeout", "60"]  # (a pass takes ~5 s; a profiler that hangs must not hold the bench up)
+           "--timeout", "45"]  # (a pass takes ~5 s; a profiler that hangs must not hold the bench up)
     if tune:
         cmd += ["--bench-args", f"--tune {tune}"]
     try:
         p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE, timeout=135)
-        d = json.load(open(out))
+                           stderr=subprocess.PIPE, timeout=100)
+        with open(out) as f:
+            d = json.load(f)
         if "read_bytes_per_frame" not in d:
             return {"error": "; ".join(d.get("failed_groups") or []) or p.stderr.decode(errors="replace")[-300:]}
         return d
@@ -211,7 +221,15 @@ def parity_check(stree, checks, width, height, focal, fp):
         max_diff = max(max_diff, int(np.abs(d).max()))
         steps.append(int(step))
     psnr = None if worst_mse == 0.0 else round(10.0 * np.log10(255.0 ** 2 / worst_mse), 2)
+    # the longest dependent chain of the launch (roofline.model.t_chain): samples of the longest ray
+    # of the checked frames -- the launch cannot end before that ray has marched them one by one
+    longest = 0
+    for _, tr, _ in checks:
+        samples, _, _ = ob.render_maps(th, ob.make_camera(tr, width, height, focal), opt, mode,
+                                       nthreads=os.cpu_count() or 1)
+        longest = max(longest, int(samples.max()))
     return {"frames_checked": len(checks), "steps": steps, "rgba8_equal": equal,
+            "longest_ray_samples": longest,
             "psnr_db": "inf" if psnr is None else psnr, "max_abs_diff_rgb8": max_diff,
             "against": f"oracle ({fp} mode; == the reference's render_kernel compiled for the host, "
                        "tests/test_oracle_vs_ref.py), frames taken from the timed region"}
@@ -275,6 +293,10 @@ def main():
                     help="measure the L2<->fabric traffic of THIS run's launch shape with two rocprofv3 "
                          "--pmc passes after the timed region (1), or report the committed, hash-verified "
                          "measurement only (0); -1 = live when rocprofv3 is on the PATH, one GPU, config C1")
+    ap.add_argument("--cold", type=int, default=1,
+                    help="after the repeats, time the identical K-step region once more behind 50 ms of "
+                         "idling (ms_per_step_cold: a launch out of an idle GPU, the condition rounds 1-3 "
+                         "measured -- both conditions in one line); 0 = skip")
     ap.add_argument("--repeats", type=int, default=5,
                     help="after the timed region, the identical K-step region is run this many more "
                          "times (not part of value / ms_per_step): the line's own noise floor")
@@ -548,6 +570,31 @@ def main():
             dt = float(tr_.item())
         repeat_ms.append(dt / K * 1e3)
 
+    # ---- the same region out of an idle GPU: 50 ms without work, then the K steps (no pre-roll, no
+    # warm-up in front: what a lone launch costs a caller that renders now and then) ----
+    cold_ms = None
+    if args.cold:
+        barrier()
+        torch.cuda.synchronize()
+        time.sleep(0.05)
+        t_cold = time.perf_counter()
+        run(K, args.warmup)
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t_cold
+        if use_dist:
+            tr_ = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else dev)
+            dist.all_reduce(tr_, op=dist.ReduceOp.MAX)
+            dt = float(tr_.item())
+        cold_ms = dt / K * 1e3
+
+    # every launch of the timed region has run: rays cut by the sample guard would mean wrong frames
+    # behind a good-looking number (vr_render* only enqueues and cannot say so itself)
+    st = tree.status()
+    if st != 0:
+        raise SystemExit(f"[bench r{rank}] render status 0x{st:x}: rays hit the sample guard -- the frames "
+                         f"of this run are wrong, no result line")
+
     if os.environ.get("VR_TIMELINE"):  # profiling build (-DVR_TIMELINE=1): per-phase cycle sums
         tl = tree.sched_stats()
         tot = max(sum(list(tl.values())[:5]), 1)
@@ -591,6 +638,10 @@ def main():
     live, committed_note = None, None
     want_live = args.live_traffic == 1 or (args.live_traffic < 0 and args.config == "C1")
     if world == 1 and rank == 0 and want_live and not args.readback and n_streams == 1:
+        # the child processes of the live passes upload the tree themselves: this process is done
+        # with the GPU, so its copy (and the frame sets) go first
+        tree.free_device()
+        tree = None
         live = live_traffic(args.config, args.fp, launch_sizes[0], args.tune)
     if world == 1:
         per_frame, traffic_src, profiled_fpl = committed_traffic(args.config, args.fp,
@@ -617,6 +668,10 @@ def main():
                                 f"launch size, not measured at it")
 
     kernel_name = "render_kernel"
+    parity = None
+    if rank == 0 and parity_frames:
+        parity = parity_check(stree, parity_frames, W, H, focal, args.fp)
+        log(f"[bench] parity vs oracle: {parity}")
     if rank == 0:
         # replicas: every rank rendered its own K frames; tile mode: the K frames were shared
         rays_total = W * H * K * (world if replicas else 1)
@@ -690,6 +745,10 @@ def main():
                     k: int(np.mean([u[k] for u in unique_frames])) for k in unique_frames[0]},
             },
         }
+        if cold_ms is not None:
+            result["ms_per_step_cold"] = round(cold_ms, 5)
+            result["cold_is"] = ("the identical K-step region once more behind 50 ms of idling (no pre-roll, "
+                                 "no warm-up in front): a launch out of an idle GPU, the condition of rounds 1-3")
         if repeat_ms:
             allms = sorted([elapsed / K * 1e3] + repeat_ms)
             result["repeats"] = {
@@ -711,9 +770,34 @@ def main():
             "salu_insts_per_frame": prof.get("salu_insts_per_frame"),
             "valu_source": committed_note if prof else "no hash-verified PMC profile of these sources",
         }
-        if parity_frames:
-            result["parity"] = parity_check(stree, parity_frames, W, H, focal, args.fp)
-            log(f"[bench] parity vs oracle: {result['parity']}")
+        if parity is not None:
+            result["parity"] = parity
+        # roofline.model: the kernel's OWN lower bounds per launch, each from a measurement -- the
+        # algorithmic `frac` above saturates (its bytes are the reference's root-to-leaf reads, which
+        # this kernel mostly serves from two cached lookups), this one keeps its headroom visible
+        fpl = launch_sizes[0]
+        bounds = {}
+        if traffic is not None:
+            bounds["t_fabric_ms"] = traffic / 128.0 / GATHER_LINES_PER_S * 1e3
+        if prof.get("valu_insts_per_frame"):
+            bounds["t_issue_ms"] = (prof["valu_insts_per_frame"] * fpl * VALU_ISSUE_CYCLES /
+                                    (N_SIMD * SIMD_HZ) * 1e3)
+        if parity is not None and parity.get("longest_ray_samples"):
+            bounds["t_chain_ms"] = parity["longest_ray_samples"] * ROUND_FLOOR_US * 1e-3
+        if bounds:
+            binding = max(bounds, key=bounds.get)
+            result["roofline"]["model"] = {
+                **{k: round(v, 5) for k, v in bounds.items()},
+                "binding": binding,
+                "kernel_ms": round(kern_mean_s * 1e3, 5),
+                "frac_of_model": round(bounds[binding] / (kern_mean_s * 1e3), 4),
+                "what": "lower bounds of ONE launch: t_fabric = measured L2<->fabric lines / the chip's "
+                        f"random-line rate ({GATHER_LINES_PER_S / 1e9:.1f} G lines/s, profiles/r01_gather_ceiling.txt); "
+                        f"t_issue = vector instructions (hash-verified PMC profile) x {VALU_ISSUE_CYCLES:.0f} cycles / "
+                        f"({N_SIMD} SIMDs x {SIMD_HZ / 1e9:.1f} GHz); t_chain = samples of the longest ray of the "
+                        f"checked frames x {ROUND_FLOOR_US} us (a dependent march round of a lone wave, "
+                        "profiles/r05_tail_profile.jsonl); frac_of_model = the largest / the launch's duration",
+            }
         if use_dist:
             result["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                               "nccl_version": ".".join(map(str, torch.cuda.nccl.version()))
@@ -728,7 +812,8 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    tree.free_device()
+    if tree is not None:
+        tree.free_device()
 
 
 if __name__ == "__main__":

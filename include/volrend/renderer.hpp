@@ -69,7 +69,9 @@ struct VolumeRenderer {
     // Throws if a launch reported rays cut by the sample guard (check_render_status,
     // volrend/renderer_kernel.hpp): a wrong frame is not handed out as a good one.
     void read_frame(void* host_rgba8);
-    // The stream render() enqueues on (hipStream_t)
+    // The stream (hipStream_t) the last render() was enqueued on: frame() is complete once it is
+    // idle.  The two frames alternate between two streams of their own, so that a render() issued
+    // before the previous frame has been consumed starts under that launch's tail.
     void* stream() const;
 
    private:

@@ -4,7 +4,8 @@
 // compositing path (offscreen = 0).
 //
 //   renderer_check <tree.npz> <spec.txt> <out.raw>
-// spec: "size W H FX FY", "background_brightness b", "step_size s", "underlay <rgba.raw> <depth.raw>" (optional),
+// spec: "size W H FX FY", "background_brightness b", "step_size s", "burst n" (render() n times per camera),
+//       "underlay <rgba.raw> <depth.raw>" (optional),
 //       one "cam cx cy cz bx by bz" per frame (camera centre and v_back; v_world_up stays +z).
 // stdout: one "transform f0 .. f11" line per frame (what Camera::_update made of the vectors)
 //         and "basis_minmax a b backend NAME".
@@ -31,7 +32,7 @@ int main(int argc, char* argv[]) {
         VolumeRenderer r;
         if (r.frame() != nullptr) return 6;  // nothing rendered yet
         std::ifstream spec(argv[2]);
-        int w = 0, h = 0;
+        int w = 0, h = 0, burst = 1;
         std::string under_rgba, under_depth;
         std::vector<std::vector<float>> cams;
         for (std::string line; std::getline(spec, line);) {
@@ -41,6 +42,7 @@ int main(int argc, char* argv[]) {
             if (key == "size") is >> w >> h >> r.camera.fx >> r.camera.fy;
             else if (key == "background_brightness") is >> r.options.background_brightness;
             else if (key == "step_size") is >> r.options.step_size;
+            else if (key == "burst") is >> burst;
             else if (key == "underlay") is >> under_rgba >> under_depth;
             else if (key == "cam") {
                 std::vector<float> c(6);
@@ -65,7 +67,9 @@ int main(int argc, char* argv[]) {
         for (size_t i = 0; i < cams.size(); ++i) {
             r.camera.center = glm::vec3(cams[i][0], cams[i][1], cams[i][2]);
             r.camera.v_back = glm::vec3(cams[i][3], cams[i][4], cams[i][5]);
-            r.render();
+            // burst > 1: render() again before the previous frame is consumed -- the two frames
+            // alternate between two streams, consecutive launches overlap; the LAST frame is read
+            for (int b = 0; b < burst; ++b) r.render();
             r.read_frame(host.data() + (size_t)w * h * 4 * i);
             const float* t = glm::value_ptr(r.camera.transform);
             printf("transform");

@@ -89,10 +89,10 @@ def test_ndc_chain(torch_cuda):
 @pytest.mark.parametrize("fp_mode", [0, 1])
 def test_random_sweep(torch_cuda, fp_mode):
     """The seeded random configurations of the CPU pin (formats, odd sizes, cameras inside the
-    volume, degenerate thresholds, bbox, basis range, rotation, depth mode, NDC), through both
-    kernel organisations and both FP models."""
-    # VR_SWEEP_SEEDS=N widens the sweep for a one-off hunt (round 3: 600 seeds, both kernel
-    # organisations, both FP models: clean -- profiles/r03_seed_sweep.txt)
+    volume, degenerate thresholds, bbox, basis range, rotation, depth mode, NDC), through the
+    kernel in both FP models."""
+    # VR_SWEEP_SEEDS=N widens the sweep for a one-off hunt (every round's final kernel: 600 seeds,
+    # both FP models, clean -- profiles/r0N_seed_sweep.txt)
     import os
     for seed in range(int(os.environ.get("VR_SWEEP_SEEDS", "24"))):
         tree, tr, w, h, f, ndc, kw, tag = common.random_configuration(seed)

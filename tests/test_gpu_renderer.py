@@ -47,6 +47,8 @@ def test_volume_renderer_matches_oracle_compositing(exe, tmp_path, underlay, bri
     npz = str(tmp_path / "t.npz")
     synth.save_npz(tree, npz, compressed=False)
     spec = [f"size {w} {h} {f!r} {f!r}", f"background_brightness {brightness!r}"]
+    if underlay and brightness < 1.0:
+        spec.append("burst 3")  # render() three times before the frame is read: both frame streams in flight
     rng = np.random.default_rng(7)
     if underlay:  # what a mesh pass would leave behind: colour + a depth that ends part of the rays
         rgba0 = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)

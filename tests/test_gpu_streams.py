@@ -125,9 +125,9 @@ def test_per_tree_tuning_and_tile_reserve(torch_cuda):
     tree = common.small_scene(depth=6, basis_dim=9, seed=515)
     a = api.N3Tree.from_synth(tree)
     b = api.N3Tree.from_synth(tree)
-    a.set_tuning(flush_wait=6, refill_min=8, march_max=4)
+    a.set_tuning(drain_flush=6, refill_min=8, march_max=4)
     b.set_tuning(refill_min=40, waves_per_cu=12)
-    c = a.clone_to(0)  # inherits flush_wait=6, refill_min=8, march_max=4
+    c = a.clone_to(0)  # inherits drain_flush=6, refill_min=8, march_max=4
     for bad_key in ("top_levels", "brick_levels", "no_such_knob"):
         with pytest.raises(_abi.VolrendError):
             a.set_tuning(**{bad_key: 3})

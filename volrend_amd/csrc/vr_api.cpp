@@ -38,7 +38,8 @@ int fail(int code, const char* fmt, ...) {
 struct Tuning {
     int march_max = 12;
     int refill_min = 20;
-    int flush_wait = 0;    // partial shade round once this many ended rays wait for colour (0 = off)
+    int drain_flush = 16;  // drain phase: partial round for a blocked ray when <= this many lanes march (0 = off;
+                           // measured 4..64, profiles/r05_experiments.jsonl: one frame per launch -13 %, two / four -5 %)
     int waves_per_cu = 0;   // 0: what the kernel flavour fits (vr_kernels.hip waves_per_cu<>)
     int frame_group = 0;   // poses per ray-order group (0 = all poses of the launch, 1 = frame-major)
     int super_block = 1;   // 8x8 blocks per super-block edge in the ray order
@@ -56,7 +57,7 @@ Tuning& default_tuning_locked() {  // call with g_tuning_mutex held
         Tuning x;
         if (const char* e = getenv("VR_MARCH_MAX")) x.march_max = atoi(e) < 1 ? 1 : atoi(e);
         if (const char* e = getenv("VR_REFILL_MIN")) x.refill_min = atoi(e) < 1 ? 1 : atoi(e);
-        if (const char* e = getenv("VR_FLUSH_WAIT")) x.flush_wait = atoi(e) < 0 ? 0 : atoi(e);
+        if (const char* e = getenv("VR_DRAIN_FLUSH")) x.drain_flush = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("VR_WAVES_PER_CU")) x.waves_per_cu = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("VR_FRAME_GROUP")) x.frame_group = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("VR_SUPER_BLOCK")) x.super_block = atoi(e) < 1 ? 1 : atoi(e);
@@ -77,7 +78,7 @@ Tuning default_tuning() {
 bool set_tuning_key(Tuning& tn, const char* key, int value) {
     if (!strcmp(key, "march_max")) tn.march_max = value < 1 ? 1 : value;
     else if (!strcmp(key, "refill_min")) tn.refill_min = value < 1 ? 1 : (value > 64 ? 64 : value);
-    else if (!strcmp(key, "flush_wait")) tn.flush_wait = value < 0 ? 0 : (value > 64 ? 64 : value);
+    else if (!strcmp(key, "drain_flush")) tn.drain_flush = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "waves_per_cu")) tn.waves_per_cu = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (!strcmp(key, "frame_group")) tn.frame_group = value < 0 ? 0 : value;
     else if (!strcmp(key, "super_block")) tn.super_block = value < 1 ? 1 : (value > 64 ? 64 : value);
@@ -1335,7 +1336,7 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
                                       : (t->array_bytes[2] + t->array_bytes[3] > (128ull << 20));
     k.march_max = tn.march_max;
     k.refill_min = tn.refill_min;
-    k.flush_wait = tn.flush_wait;
+    k.drain_flush = tn.drain_flush;
     k.max_iter = tn.max_iter;
     k.frame_group = tn.frame_group < 1 || tn.frame_group > n_frames ? n_frames : tn.frame_group;
     k.super_block = tn.super_block;

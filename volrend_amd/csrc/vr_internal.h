@@ -98,7 +98,8 @@ struct KParams {
                                  // evaluated when a lane takes the ray
     int32_t refill_min;          // refill once this many lanes are idle
     int32_t march_max;           // march steps per lane between two shade checks
-    int32_t flush_wait;          // shade a partial round once this many ended rays wait for colour (0 = never)
+    int32_t drain_flush;         // drain phase: a ray blocked by its full colour queue gets a partial shade round
+                                 // at once when at most this many lanes of the wave still march (0 = never)
     int32_t max_iter;            // guard: march rounds of a wave without a retired ray before it cuts its rays
     int32_t instrumented;        // any frame carries counters -> FULL flavour
     int32_t any_accum;           // some frame of the launch asks for its fp32 accumulators

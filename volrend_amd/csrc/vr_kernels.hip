@@ -1324,13 +1324,19 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 // march step would let the ring overflow)
                 while (ring_tail - ring_head >= (uint32_t)ST::kShade) shade_chunk(ST::kShade);
             }
-            // Lanes whose ray has ended but still has colour items queued can neither march nor
-            // be refilled: once flush_wait of them idle, a partial shade round frees them (the
-            // round costs what a full one costs, so the threshold is a trade: measured below).
-            if (p.flush_wait > 0) {
-                const unsigned long long m_wait =
-                    __builtin_amdgcn_ballot_w64(ray.active && !(ray.t < ray.tmax) && qsh < 32u);
-                if (__builtin_popcountll(m_wait) >= p.flush_wait && ring_tail != ring_head) {
+            // Drain phase (the ray queues have run dry): a ray whose colour queue is full cannot
+            // march until a shade round takes its items, and a round waits for 64 items or for the
+            // moment NOBODY can march -- with few rays left in the wave the blocked ray waits for the
+            // other rays to fill their queues too, i.e. the last rays of a launch take turns instead
+            // of marching side by side (a one-frame launch ran 526 rounds in its longest-lived wave
+            // for a longest ray of 230 samples; without colour work 279:
+            // profiles/r05_tail_profile.jsonl).  So once the wave is down to drain_flush marching
+            // lanes, a blocked ray gets a (partial) round at once.  (A partial round costs what a
+            // full one costs: while the queues still feed the wave this would be a loss.)
+            if (exhausted) {
+                const unsigned long long m_alive = __builtin_amdgcn_ballot_w64(ray.t < ray.tmax);
+                if (__builtin_popcountll(m_alive) <= p.drain_flush &&
+                    (m_alive & __builtin_amdgcn_ballot_w64(qsh == 0u)) != 0ull && ring_tail != ring_head) {
                     const uint32_t waiting = ring_tail - ring_head;
                     shade_chunk(waiting < (uint32_t)ST::kShade ? (int)waiting : ST::kShade);
                 }
