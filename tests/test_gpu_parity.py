@@ -309,20 +309,24 @@ def test_random_configurations_bit_exact(torch_cuda, fp_mode):
 
 
 @pytest.mark.parametrize("fp_mode", [0, 1])
-@pytest.mark.parametrize("top_levels,brick_levels", [(1, 1), (1, 3), (1, 4), (2, 2), (2, 3), (2, 4), (3, 3), (3, 4), (4, 1),
-                                                     (5, 2), (6, 3), (8, 3)])
-def test_lookup_structure_geometries(torch_cuda, top_levels, brick_levels, fp_mode):
+@pytest.mark.parametrize("top_levels,brick_levels,blocked",
+                         [(1, 1, 0), (1, 3, 0), (1, 4, 0), (2, 2, 0), (2, 3, 0), (2, 4, 0), (3, 3, 0), (3, 4, 0),
+                          (4, 1, 0), (5, 2, 0), (6, 3, 0), (8, 3, 0),
+                          # bricks in 4 x 4 x 2 line blocks (the entry order large trees get at upload)
+                          (1, 3, 1), (2, 3, 1), (3, 3, 1), (4, 3, 1), (6, 3, 1), (2, 4, 1)])
+def test_lookup_structure_geometries(torch_cuda, top_levels, brick_levels, blocked, fp_mode):
     """The N == 2 lookup structure (top grid of 2^G0 cells per axis + bricks of 2^BL entries per
     axis + child words below, vr_kernels.hip) is a pure index: whatever its geometry, every
     sample must land in the leaf the reference's root descent finds (n3tree_query.hpp:13-48).
     Small geometries push a depth-7 tree through every branch: top leaves, brick leaves of all
-    three depths, and the child-word walk below the bricks."""
+    three depths, and the child-word walk below the bricks -- in both entry orders of the bricks
+    (brick_blocked applies to 8^3 bricks only: (2, 4, 1) must quietly stay x-major)."""
     from volrend_amd import api
     tree = common.small_scene(depth=7, basis_dim=4, seed=1201)
     tr, w, h, f = common.camera_for(pose_idx=3, size=72)
     rgba_o, acc_o, cnt = common.oracle_frame(tree, tr, w, h, f, fp_mode)
     assert cnt["hit_samples"] > 1000
-    api.set_tuning(top_levels=top_levels, brick_levels=brick_levels)
+    api.set_tuning(top_levels=top_levels, brick_levels=brick_levels, brick_blocked=blocked)
     try:
         rgba_g, acc_g = gpu_frame(torch_cuda, tree, tr, w, h, f, fp_mode)
         # instrumented flavour: child_reads = sum of leaf depths must match the oracle's walk
@@ -339,7 +343,7 @@ def test_lookup_structure_geometries(torch_cuda, top_levels, brick_levels, fp_mo
         cnt_g = dict(zip(_abi.COUNTER_FIELDS, [int(v) for v in counters.cpu().tolist()]))
         t.free_device()
     finally:
-        api.set_tuning(top_levels=0, brick_levels=3)
+        api.set_tuning(top_levels=0, brick_levels=3, brick_blocked=-1)
     assert_parity(rgba_g, acc_g, rgba_o, acc_o)
     assert cnt_g == cnt
     assert np.array_equal(img.cpu().numpy(), rgba_o)

@@ -2,17 +2,17 @@
 # ~8 GPU-minutes.  Everything lands in gpurun_out/<tag>/; the traffic JSONs are also copied to
 # profiles/ at once so that the bench lines taken afterwards can report them (source hash verified).
 set -u
-R=${1:-r04}
+R=${1:-r05}
 mkdir -p gpurun_out/$R
 export TMPDIR=/tmp
 O=gpurun_out/$R
 timeout 1800 python -m pytest tests -m gpu -x -q --timeout 900 > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 # --- PMC traffic first: C1 at 64, 20 (the driver's launch shape) and 1 frames per launch, C2 / C3 read sizes + L2
 timeout 900 python tools/measure_traffic.py --config C1 --groups rdsize write fetch tcc sq1 sq2 --out $O/${R}_traffic_C1.json > /dev/null 2> $O/traffic_C1.log; tail -1 $O/traffic_C1.log
-timeout 900 python tools/measure_traffic.py --config C1 --batch 20 --groups rdsize write tcc --out $O/${R}_traffic_C1_20.json > /dev/null 2> $O/traffic_C1_20.log; tail -1 $O/traffic_C1_20.log
+timeout 900 python tools/measure_traffic.py --config C1 --batch 20 --groups rdsize write tcc sq1 sq2 --out $O/${R}_traffic_C1_20.json > /dev/null 2> $O/traffic_C1_20.log; tail -1 $O/traffic_C1_20.log
 timeout 900 python tools/measure_traffic.py --config C1 --batch 1 --groups rdsize write sq1 sq2 --out $O/${R}_traffic_C1_1.json > /dev/null 2> $O/traffic_C1_1.log; tail -1 $O/traffic_C1_1.log
 for c in C2 C3; do
-  timeout 900 python tools/measure_traffic.py --config $c --groups rdsize write tcc --out $O/${R}_traffic_$c.json > /dev/null 2> $O/traffic_$c.log; tail -1 $O/traffic_$c.log
+  timeout 900 python tools/measure_traffic.py --config $c --groups rdsize write tcc sq1 sq2 --out $O/${R}_traffic_$c.json > /dev/null 2> $O/traffic_$c.log; tail -1 $O/traffic_$c.log
 done
 cp $O/${R}_traffic_*.json profiles/
 # --- bench lines
@@ -25,6 +25,11 @@ VOLREND_FORCE_GATHER=1 timeout 300 python bench.py --no-cpu-baseline > $O/${R}_b
 # --- launch shape: frames per launch (steady state, quick_ab with fresh poses per launch) and lone launches as the driver times them
 timeout 600 python tools/quick_ab.py --config C1 --variants base --tunes "" --frames 64,20,8,4,2,1 --reps 4 --rotate --out $O/${R}_launch_shape.jsonl > $O/launch_shape.log 2>&1
 bash tools/lone_launch.sh $R > /dev/null 2>&1; cp gpurun_out/lone_$R.jsonl $O/${R}_lone_launch.jsonl
+# --- small launches: anatomy (kernel trace), one / two alternating streams, the dependent round in an empty / full chip
+timeout 600 python tools/launch_anatomy.py --out $O/${R}_launch_anatomy.jsonl > $O/anatomy.log 2>&1
+timeout 600 python tools/stream_overlap.py --frames 1,2,4,8 --streams 1,2 --out $O/${R}_stream_overlap.jsonl > $O/overlap.log 2>&1
+timeout 600 python tools/round_time_probe.py --out $O/${R}_round_time_probe.jsonl > $O/round_time.log 2>&1
+VOLREND_HIP_LIB=$PWD/volrend_amd/libvolrend_hip_tl3.so VR_TIMELINE=3 timeout 300 python tools/tail_profile.py --frames 1 --out $O/${R}_tail_profile_final.jsonl > $O/tail.log 2>&1
 # --- rocprofv3 kernel stats of the default and of the driver's command
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o stats --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 128 --warmup 64 --no-cpu-baseline --no-parity > $GRAFT_REPO_ROOT/$O/prof_bench.json 2> $GRAFT_REPO_ROOT/$O/prof.log ); cp $O/prof/stats_kernel_stats.csv $O/${R}_final_kernel_stats.csv
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof20 -o stats --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity > $GRAFT_REPO_ROOT/$O/prof20_bench.json 2> $GRAFT_REPO_ROOT/$O/prof20.log ); cp $O/prof20/stats_kernel_stats.csv $O/${R}_driverflags_kernel_stats.csv
@@ -46,6 +51,10 @@ VR_UPLOAD_TIMING=1 timeout 900 python tools/upload_bench.py > $O/${R}_upload_ben
 # --- balance of the 8-rank tile shard (each rank's bands rendered alone on this one GPU)
 rm -f $O/${R}_shard_balance.jsonl
 timeout 900 python tools/shard_balance.py --config C3 --world 8 --tile-rows 8,16,32,64 --frames 64 --out $O/${R}_shard_balance.jsonl > /dev/null 2>&1
+# the driver's launch shape: 20 poses per launch, 2 / 4 / 8 ranks (C1: the bench's workload; C3: BASELINE config 3)
+for c in C1 C3; do for w in 2 4 8; do
+  timeout 600 python tools/shard_balance.py --config $c --world $w --tile-rows 8 --frames 20 --first-pose 5 --out $O/${R}_shard_balance.jsonl > /dev/null 2>&1
+done; done
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("$O/${R}_*bench*.json")):

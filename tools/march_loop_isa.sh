@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off \
   -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -x hip \
   -I include -I volrend_amd/csrc -S --cuda-device-only volrend_amd/csrc/vr_kernels.hip -o /tmp/vr_isa.s 2>/dev/null
-awk '/^_ZN2vr12_GLOBAL__N_113render_kernelILi0ELi16ELi0EEEvNS_7KParamsE:/,/s_endpgm/' /tmp/vr_isa.s > /tmp/vr_isa_k16.s
+awk '/^_ZN2vr12_GLOBAL__N_113render_kernelILi0ELi16ELi0ELb0EEEvNS_7KParamsE:/,/s_endpgm/' /tmp/vr_isa.s > /tmp/vr_isa_k16.s
 python3 - <<'PY'
 import re
 lines = open('/tmp/vr_isa_k16.s').read().split('\n')

@@ -115,7 +115,7 @@ def main():
     cfg = synth.CONFIGS[args.config]
     basis = cfg["basis_dim"] if cfg["fmt"] != "RGBA" else -1
     fpi = 1 if args.fp == "fma" else 0
-    kernel = f"render_kernel<{fpi}, {basis}, 0>"
+    kernel = f"render_kernel<{fpi}, {basis}, 0"  # (+ the brick-order flavour: ", false>" / ", true>")
     bench_args = ["--config", args.config, "--fp", args.fp, "--batch", str(args.batch), "--steps",
                   str(2 * args.batch), "--warmup", str(args.batch), "--no-cpu-baseline", "--no-parity",
                   "--live-traffic", "0", "--repeats", "0", "--preroll", "0",

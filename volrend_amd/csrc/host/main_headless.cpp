@@ -173,10 +173,10 @@ int main(int argc, char* argv[]) {
     args.add("reverse_yz", 'r', true, "", "use OpenCV camera space convention instead of NeRF");
     args.add("scale", 0, false, "1.0", "scaling to apply to image");
     args.add("max_imgs", 0, false, "0", "max images to render, default no limit");
-    args.add("batch", 0, false, "32",
+    args.add("batch", 0, false, "64",
              "poses per launch and GPU (1..512): a launch carries batch x max(1, --gpus) poses, at "
-             "most 512, and the pose list is cut into EQUAL launches (200 poses at 32: 7 launches "
-             "of 29 / 28 -- no short last launch)");
+             "most 512, and the pose list is cut into EQUAL launches (200 poses at 64: 4 launches "
+             "of 50 -- no short last launch)");
     args.add("streams", 0, false, "0",
              "render streams the launches alternate between (1 or 2; 0 = auto: 2 when a launch "
              "carries fewer than 8 poses).  A launch drains for ~0.3 ms while its longest rays "

@@ -52,6 +52,7 @@ struct KParams {
     int32_t max_depth;        // deepest leaf level (child words read - 1)
     int32_t top_levels;       // G0: the top grid has 2^G0 cells per axis (0 = no lookup structure)
     int32_t brick_levels;     // BL: a brick has 2^BL entries per axis (0 = no bricks)
+    int32_t brick_blocked;    // 8^3 bricks stored in 4 x 4 x 2 line blocks (per tree, fixed at upload)
     float ndc_width, ndc_height, ndc_focal;
     // ---- camera intrinsics (CameraSpec, data_spec.hpp:11-22); poses are per frame ----
     int32_t width, height;
@@ -138,6 +139,6 @@ hipError_t launch_popcount(const uint32_t* words, uint64_t n_words, unsigned lon
 // N == 2 lookup structure (top grid + bricks), built from the re-laid-out node words
 hipError_t launch_build_lookup(const uint32_t* nodes, const int32_t* brick_root, int n_bricks,
                                uint2* top, uint32_t* bricks, int top_levels, int brick_levels,
-                               uint32_t* error_flag, hipStream_t stream);
+                               int brick_blocked, uint32_t* error_flag, hipStream_t stream);
 
 }  // namespace vr

@@ -41,7 +41,8 @@ constexpr int kWave = 64;
 #define VR_SH25_WAVES 4  // (5 = 96 VGPRs + 64 B of scratch with fenced shade math: measured 30 % slower)
 #endif
 #ifndef VR_SH9_WAVES
-#define VR_SH9_WAVES 6  // (7 fits the LDS but needs 72 VGPRs: scratch)
+#define VR_SH9_WAVES 7  // (72 VGPRs without scratch since the lane's ray id lives in LDS and the round counters in
+                        // scalar registers: round 5; C3 -1...-3 % against 6)
 #endif
 #ifndef VR_PACKED_EXP
 #define VR_PACKED_EXP 1       // the sigmoids of channels 0/1 share packed mul / fma / add instructions
@@ -171,6 +172,13 @@ __device__ __forceinline__ void precalc_basis(const KParams& p, const float* dir
 //                    next BL - 1 levels are numbered right behind it: delta <= 8 + 64 + 512)
 //        bit31 = 0 : an internal node of level G0 + BL: its index; the walk continues there
 //                    with one child-word load per level.
+//        Entry order inside a brick: x-major (index = x << 2 BL | y << BL | z: a 128-byte line is a
+//        1 x 4 x 8 slab of an 8^3 brick), or -- KParams.brick_blocked, BL == 3 only, chosen per tree
+//        at upload -- [x2 y2 z2 z1 | x1 x0 y1 y0 z0]: a line is a 4 x 4 x 2 block, which a ray
+//        crosses 3.5 instead of 4.8 of per brick.  The blocked order costs six more vector
+//        instructions per brick lookup, so it is for trees whose lookups are fabric traffic: C3
+//        (286 MB of lookup structure) -15 % L2<->fabric bytes, -3 % frame time; C1 / C2 (92 MB)
+//        +1 % / +4 % (profiles/r05_experiments.jsonl, r05d).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr int kMaxBrickLevels = 4;   // delta field (10 bits): 8 + 64 + 512 nodes below a brick root
@@ -235,7 +243,10 @@ struct Cursor {
 // chain, and the digits of several levels index a table at once.
 // Valid while the deepest leaf has d <= 24 (checked at upload).
 // Returns the leaf id; *depth = d (child words the reference reads = d), *word low 16 bits = sigma.
-template <bool COUNT = false>
+// BLK: entry order of the bricks -- 0 x-major, 1 blocked (both compile-time: the production flavours
+// exist once per order, a launch-uniform branch in the march round costs C1 1.5 %), -1 = as
+// KParams.brick_blocked says (the instrumented flavours).
+template <bool COUNT = false, int BLK = -1>
 __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* depth,
                                              uint32_t* word, Cursor& cur) {
     // clamp to [0, 1 - 1e-6] (n3tree_query.hpp:17-19) as ONE v_med3_f32 per axis: identical to
@@ -266,9 +277,22 @@ __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* 
         d = (int)__builtin_amdgcn_ubfe(w, 16u, 5u);
     } else {
         const uint32_t bl = (uint32_t)p.brick_levels, sh1 = sh0 - bl;
-        const uint32_t sub = (((__builtin_amdgcn_ubfe(ux, sh1, bl) << bl) |
-                               __builtin_amdgcn_ubfe(uy, sh1, bl)) << bl) |
-                             __builtin_amdgcn_ubfe(uz, sh1, bl);
+        uint32_t sub;
+        if (BLK > 0 || (BLK < 0 && p.brick_blocked)) {  // (compile-time, or launch-uniform)
+            // 8^3 bricks in entry order [x2 y2 z2 z1 | x1 x0 y1 y0 z0]: a 128-byte line holds a
+            // 4 x 4 x 2 block of entries instead of a 1 x 4 x 8 slab -- a ray crosses 3.5 lines of
+            // a brick instead of 4.8 (chosen per tree at upload: layout comment at the top)
+            const uint32_t lo = (((__builtin_amdgcn_ubfe(ux, sh1, 2u) << 2) |
+                                  __builtin_amdgcn_ubfe(uy, sh1, 2u)) << 1) |
+                                __builtin_amdgcn_ubfe(uz, sh1, 1u);
+            const uint32_t hi = (((__builtin_amdgcn_ubfe(ux, sh1 + 2u, 1u) << 1) |
+                                  __builtin_amdgcn_ubfe(uy, sh1 + 2u, 1u)) << 2) |
+                                __builtin_amdgcn_ubfe(uz, sh1 + 1u, 2u);
+            sub = (hi << 5) | lo;
+        } else {
+            sub = (((__builtin_amdgcn_ubfe(ux, sh1, bl) << bl) | __builtin_amdgcn_ubfe(uy, sh1, bl)) << bl) |
+                  __builtin_amdgcn_ubfe(uz, sh1, bl);
+        }
         const uint32_t entry = (w << (3u * bl)) + sub;
         if (COUNT) touch(p, TOUCH_BRICKS, (uint64_t)entry * 4u, 4u);
         w = VR_EXP_BRICK_WORD(*reinterpret_cast<const uint32_t*>(
@@ -493,6 +517,13 @@ typedef float vr_f4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) vr_f4_t vr_gfloat4_t;
 
 __device__ __forceinline__ bool wave_any(bool v) { return __builtin_amdgcn_ballot_w64(v) != 0ull; }
+// The lane's id, recomputed where it is asked for (two instructions): for addresses that are needed
+// once in a while -- a register that holds `lane * 4` across the march loop is one the hot path lacks.
+__device__ __forceinline__ uint32_t lane_id_now() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 
 // ---------------------------------------------------------------------------
 // render_kernel: render_kernel + trace_ray of the reference
@@ -904,8 +935,8 @@ __device__ __forceinline__ void issue_records(const KParams& p, char* stage, con
 }
 
 // Register budget of the fused FAST flavours (waves per SIMD), from their natural register use:
-// SH16 96 VGPRs -> VR_SH16_WAVES = 5 (20 waves per CU; 6 needs <= 80 and spills), SH9 <= 80 ->
-// VR_SH9_WAVES = 6, SH25 <= 128 -> 4 (it gathers its 25 basis values up front), the small
+// SH16 96 VGPRs -> VR_SH16_WAVES = 5 (20 waves per CU; 6 needs <= 80 and spills), SH9 <= 72 ->
+// VR_SH9_WAVES = 7, SH25 <= 128 -> 4 (it gathers its 25 basis values up front), the small
 // records 8.  The instrumented / lobe / generic flavours keep their wider state in registers at
 // 4 waves per SIMD (3 for SH25).  No render flavour uses scratch.
 template <int BASIS, int MODE>
@@ -917,12 +948,12 @@ constexpr int min_waves_per_eu() {
 // Waves one CU holds of a flavour: the register bound above or the LDS bound (512-byte granules).
 template <int BASIS, int MODE>
 constexpr int waves_per_cu() {
-    const int lds = ((kRing * 9 + Stage<BASIS>::kBytes + 511) / 512) * 512;
+    const int lds = ((kRing * 9 + kWave * 4 + Stage<BASIS>::kBytes + 511) / 512) * 512;
     const int by_lds = 163840 / lds, by_reg = 4 * min_waves_per_eu<BASIS, MODE>();
     return by_lds < by_reg ? by_lds : by_reg;
 }
 
-template <int FMA, int BASIS, int MODE>
+template <int FMA, int BASIS, int MODE, bool BLK = false>
 __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void render_kernel(
     const KParams p) {
     using P = Policy<FMA>;
@@ -945,7 +976,9 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     Ray ray;
     ray.active = false;
     ray.alive = ray.entered = ray.stopped = false;
-    uint32_t ray_id = 0;  // index of the lane's ray in the ray buffer
+    // index of the lane's ray in the ray buffer: written when the lane takes the ray, read when it
+    // retires it -- in LDS, not in a register that would sit idle through every march round
+    __shared__ uint32_t ray_ids[kWave];
     ray.t = 0.f;
     ray.tmax = -1.f;
     ray.light = 1.f;
@@ -1130,7 +1163,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
             uint32_t px_lo = 0, px_hi = 0, fin_xy = 0, fin_frame = 0;
             ray.stopped = ray.tmax < 0.f;  // (read before a new ray's tmax lands in the register)
             if (done) {
-                const uint32_t* rs = ray_slot(p.ray_buf, wpr, ray_id);
+                const uint32_t* rs = ray_slot(p.ray_buf, wpr, ray_ids[lane_id_now()]);
                 px_lo = ray_word(rs, 13);
                 px_hi = ray_word(rs, 14);
                 if (COUNT || p.any_accum) {
@@ -1140,7 +1173,9 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
             }
             const bool vacant = done || !ray.active;
             bool take = false;
-            if (m_done != 0ull) progress_round = rounds;  // (a ray retired: the wave makes progress)
+            // (a ray retired: the wave makes progress.  Both counters are wave-uniform; saying so keeps
+            // them in scalar registers -- as vector values they cost the SH16 flavour its last two)
+            if (m_done != 0ull) progress_round = (uint32_t)__builtin_amdgcn_readfirstlane((int)rounds);
             // Idle lanes take consecutive rays from the buffer.  The wave owns a private
             // chunk [chunk_next, chunk_end) of ray ids and only goes to the global queue
             // head (ONE returning atomic -- a single word sustains ~90 of them per
@@ -1179,7 +1214,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     ray.t = u2f(ray_word(rs, 9));
                     ray.tmax = u2f(ray_word(rs, 10));
                     ray.delta_scale = u2f(ray_word(rs, 11));
-                    ray_id = r;
+                    ray_ids[lane_id_now()] = r;
                     if (HAS_BASIS && VR_EXP_FUSED_COLOUR) {
                         if (BASIS > 1 && p.ray_vdir) {
                             // rt_core.cuh:96-103: the basis of the ray's view direction (SH:
@@ -1265,7 +1300,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 int levels;
                 uint32_t word;
                 if (N2) {
-                    leaf = query_n2<COUNT>(p, pos, &levels, &word, cur);
+                    leaf = query_n2<COUNT, (MODE == MODE_FAST ? (BLK ? 1 : 0) : -1)>(p, pos, &levels, &word, cur);
                 } else {
                     leaf = (uint32_t)query_generic<FMA, COUNT>(p, pos, &cube_sz, &levels, &word);
                 }
@@ -1342,7 +1377,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 }
             }
         }
-        rounds += (uint32_t)m;
+        rounds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rounds + (uint32_t)m));
         // nobody can march any more (queues full / rays ended): flush what is queued
         // (at most kShade - 1 + 64 items wait here: two rounds at most)
         while (ring_tail != ring_head && !wave_any(ray.t < ray.tmax && qsh > 0u)) {
@@ -1701,13 +1736,18 @@ __global__ void build_top_kernel(const uint32_t* nodes, const int32_t* brick_roo
 
 // Lookup structure, part 2: one thread per brick entry.
 __global__ void build_bricks_kernel(const uint32_t* nodes, const int32_t* brick_root, int n_bricks,
-                                    uint32_t* bricks, int BL, uint32_t* error_flag) {
+                                    uint32_t* bricks, int BL, int blocked, uint32_t* error_flag) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t per = 1u << (3 * BL);
     if (gid >= (uint64_t)n_bricks * per) return;
     const uint32_t b = (uint32_t)(gid >> (3 * BL)), e = (uint32_t)gid & (per - 1u);
     const uint32_t mask = (1u << BL) - 1u;
-    const uint32_t ex = (e >> (2 * BL)) & mask, ey = (e >> BL) & mask, ez = e & mask;
+    uint32_t ex = (e >> (2 * BL)) & mask, ey = (e >> BL) & mask, ez = e & mask;
+    if (blocked) {  // BL == 3: e = [x2 y2 z2 z1 | x1 x0 y1 y0 z0] (query_n2)
+        ex = (((e >> 8) & 1u) << 2) | ((e >> 3) & 3u);
+        ey = (((e >> 7) & 1u) << 2) | ((e >> 1) & 3u);
+        ez = (((e >> 5) & 3u) << 1) | (e & 1u);
+    }
     const uint32_t root = (uint32_t)brick_root[b];
     uint32_t node = root;
     for (int k = 0; k < BL; ++k) {
@@ -1748,7 +1788,10 @@ hipError_t launch_basis(const KParams& p, int64_t want, int n_cus, int waves_ove
         const int64_t cap_ = (int64_t)n_cus * (waves_override > 0 ? waves_override           \
                                                                   : waves_per_cu<B, MODE>()); \
         const dim3 grid((unsigned)(want < cap_ ? want : cap_));                              \
-        hipLaunchKernelGGL((render_kernel<FMA, B, MODE>), grid, block, 0, s, p);             \
+        if (MODE == MODE_FAST && p.brick_blocked)                                            \
+            hipLaunchKernelGGL((render_kernel<FMA, B, MODE, MODE == MODE_FAST>), grid, block, 0, s, p); \
+        else                                                                                 \
+            hipLaunchKernelGGL((render_kernel<FMA, B, MODE, false>), grid, block, 0, s, p);  \
     } while (0)
     switch (b) {
         case BASIS_RGBA: VR_LAUNCH(BASIS_RGBA); break;
@@ -1836,6 +1879,9 @@ hipError_t launch_probe(const KParams& p, const float probe[3], float* out_dev,
 
 int leaf_stride_halfs(int data_dim) {
     const int bytes = 2 * (data_dim - 1);
+#ifdef VR_EXP_SH25_STRIDE  // experiment (r05g): SH25 records on a 256-byte stride = two whole lines each
+    if (bytes == 150) return VR_EXP_SH25_STRIDE / 2;
+#endif
     int stride = 16;
     while (stride < bytes && stride < 128) stride *= 2;  // 16, 32, 64, 128: never straddles a line
     if (stride < bytes) stride = (bytes + 31) / 32 * 32;
@@ -1856,14 +1902,15 @@ hipError_t launch_relayout(const int32_t* child, const uint16_t* data, const int
 
 hipError_t launch_build_lookup(const uint32_t* nodes, const int32_t* brick_root, int n_bricks,
                                uint2* top, uint32_t* bricks, int top_levels, int brick_levels,
-                               uint32_t* error_flag, hipStream_t stream) {
+                               int brick_blocked, uint32_t* error_flag, hipStream_t stream) {
     const uint32_t n_cells = 1u << (3 * top_levels);
     hipLaunchKernelGGL(build_top_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, stream, nodes,
                        brick_root, n_bricks, top, top_levels, error_flag);
     if (n_bricks > 0 && brick_levels > 0) {
         const uint64_t n = (uint64_t)n_bricks << (3 * brick_levels);
         hipLaunchKernelGGL(build_bricks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                           stream, nodes, brick_root, n_bricks, bricks, brick_levels, error_flag);
+                           stream, nodes, brick_root, n_bricks, bricks, brick_levels,
+                           (brick_blocked && brick_levels == 3) ? 1 : 0, error_flag);
     }
     return hipGetLastError();
 }
