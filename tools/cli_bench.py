@@ -41,14 +41,15 @@ def main():
     common = [npz, *poses, "-i", os.path.join(work, "intrinsics.txt"), "-w", str(cfg["width"]),
               "-h", str(cfg["height"])]
     out = {"config": name, "poses": len(poses)}
-    out["timing_only"] = run(common)  # default --batch 32: 200 poses -> 7 equal launches of 29 / 28
-    out["timing_only_batch64"] = run(common + ["--batch", "64"])  # 4 launches of 50
+    out["timing_only"] = run(common)  # defaults: --batch 64 (200 poses -> 4 equal launches of 50), --streams auto
+    for b in (64, 32):
+        for st in (1, 2):
+            out[f"batch{b}_streams{st}"] = run(common + ["--batch", str(b), "--streams", str(st)])
     # the reference's own launch shape -- one pose per launch -- and small launches, on one stream and
     # on two alternating ones (--streams 0 = auto picks 2 below 8 poses per launch)
     for b in (1, 4):
         for st in (1, 2):
             out[f"batch{b}_streams{st}"] = run(common + ["--batch", str(b), "--streams", str(st)])
-    out["batch32_streams2"] = run(common + ["--streams", "2"])
     # the native tile-shard path on this one-GPU box: 1 rank through RCCL (ncclCommInitAll + a
     # grouped self send/recv per launch), and a 2-rank REHEARSAL sharing the GPU (never a measurement
     # of scaling: both ranks compete for the same chip)

@@ -179,9 +179,10 @@ int main(int argc, char* argv[]) {
              "of 50 -- no short last launch)");
     args.add("streams", 0, false, "0",
              "render streams the launches alternate between (1 or 2; 0 = auto: 2 when a launch "
-             "carries fewer than 8 poses).  A launch drains for ~0.3 ms while its longest rays "
+             "carries fewer than 48 poses).  A launch drains for ~0.25 ms while its longest rays "
              "finish; on a second stream the next launch starts under that tail "
-             "(profiles/r05_stream_overlap.jsonl: one pose per launch 0.58 -> 0.40 ms per frame)");
+             "(profiles/r05_cli_bench.json: one pose per launch 0.53 -> 0.39 ms per frame, four "
+             "0.31 -> 0.29, thirty-two 0.254 -> 0.250, fifty: a tie)");
     args.add("gpus", 0, false, "0",
              "render every frame on this many GPUs (devices --gpu .. --gpu+N-1): interleaved "
              "screen tiles, tree replicated device to device, RCCL gather of the RGBA8 tiles to "
@@ -353,7 +354,7 @@ int main(int argc, char* argv[]) {
     // Render streams: launch k runs on stream k % n_streams and writes image set k % 2 -- with two
     // streams every stream owns one image set (the tile shard brings its own streams).
     int n_streams = args.as_int("streams");
-    if (n_streams <= 0) n_streams = batch < 8 ? 2 : 1;
+    if (n_streams <= 0) n_streams = batch < 48 ? 2 : 1;
     if (n_streams > 2) n_streams = 2;
     if (shard) n_streams = 1;
     hipStream_t streams[2] = {nullptr, nullptr};
@@ -378,6 +379,14 @@ int main(int argc, char* argv[]) {
         }
     };
 
+    // The launch slots' ray buffers are sized BEFORE the clock starts (two slots: one per render
+    // stream; 76 bytes per ray of a launch -- 2.4 GB at 50 poses of 800 x 800): left to the first
+    // launches, the allocations would sit inside the timed loop, as the reference's cudaArray
+    // would if it were created behind cudaEventRecord(start) (main_headless.cpp:187-203).
+    if (!shard && vr_reserve(tree.device, width, height, batch) != VR_OK) {
+        fprintf(stderr, "ERROR: %s\n", vr_last_error());
+        return 1;
+    }
     HIP_OK(hipEventRecord(start, streams[0]));
     if (n_streams > 1) HIP_OK(hipStreamWaitEvent(streams[1], start, 0));  // the clock starts before any launch
     int seq = 0;
