@@ -4,7 +4,7 @@
 set -u
 OUT=gpurun_out/lone_${1:-x}.jsonl; : > $OUT
 for spec in "20 5" "20 5" "20 105" "64 5" "40 5" "10 5" "4 5" "1 5" "1 5"; do set -- $spec
-  timeout 300 python bench.py --steps $1 --warmup $2 --batch 128 --no-cpu-baseline --no-parity 2>/dev/null | python -c '
+  timeout 300 python bench.py --steps $1 --warmup $2 --batch 128 --no-cpu-baseline --no-parity --live-traffic 0 --cold 0 --repeats 0 2>/dev/null | python -c '
 import json,sys
 for l in sys.stdin:
     d=json.loads(l); r=d["roofline"]
