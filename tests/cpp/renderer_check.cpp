@@ -5,12 +5,14 @@
 //
 //   renderer_check <tree.npz> <spec.txt> <out.raw>
 // spec: "size W H FX FY", "background_brightness b", "step_size s", "burst n" (render() n times per camera),
+//       "loop n" (afterwards: n render() calls back to back, timed -> "loop_ms_per_frame x"),
 //       "underlay <rgba.raw> <depth.raw>" (optional),
 //       one "cam cx cy cz bx by bz" per frame (camera centre and v_back; v_world_up stays +z).
 // stdout: one "transform f0 .. f11" line per frame (what Camera::_update made of the vectors)
 //         and "basis_minmax a b backend NAME".
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <fstream>
 #include <sstream>
@@ -32,7 +34,7 @@ int main(int argc, char* argv[]) {
         VolumeRenderer r;
         if (r.frame() != nullptr) return 6;  // nothing rendered yet
         std::ifstream spec(argv[2]);
-        int w = 0, h = 0, burst = 1;
+        int w = 0, h = 0, burst = 1, loop = 0;
         std::string under_rgba, under_depth;
         std::vector<std::vector<float>> cams;
         for (std::string line; std::getline(spec, line);) {
@@ -43,6 +45,7 @@ int main(int argc, char* argv[]) {
             else if (key == "background_brightness") is >> r.options.background_brightness;
             else if (key == "step_size") is >> r.options.step_size;
             else if (key == "burst") is >> burst;
+            else if (key == "loop") is >> loop;
             else if (key == "underlay") is >> under_rgba >> under_depth;
             else if (key == "cam") {
                 std::vector<float> c(6);
@@ -75,6 +78,21 @@ int main(int argc, char* argv[]) {
             printf("transform");
             for (int k = 0; k < 12; ++k) printf(" %.9g", t[k]);
             printf("\n");
+        }
+        if (loop > 0 && !cams.empty()) {
+            // a render() loop as an interactive caller runs it: `loop` frames, the camera stepping
+            // through the given ones, the frame consumed only at the end (tools/cli_bench.py)
+            (void)hipDeviceSynchronize();
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int k = 0; k < loop; ++k) {
+                const std::vector<float>& c = cams[(size_t)k % cams.size()];
+                r.camera.center = glm::vec3(c[0], c[1], c[2]);
+                r.camera.v_back = glm::vec3(c[3], c[4], c[5]);
+                r.render();
+            }
+            (void)hipDeviceSynchronize();
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            printf("loop_ms_per_frame %.5f\n", ms / loop);
         }
         // without a tree render() leaves the cleared frame / the underlay (cuda_renderer.cpp:114)
         r.clear();

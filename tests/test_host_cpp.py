@@ -231,6 +231,37 @@ def test_cli_pose_and_intrinsics_parsing(tmp_path):
     assert np.allclose(flipped["a44"][:, [0, 3]], want[:, [0, 3]], rtol=1e-6)
 
 
+def test_cli_launch_plan(tmp_path):
+    """How volrend_headless cuts its pose list into launches (round 5): ceil(P / batch) EQUAL
+    launches (sizes differ by at most one pose: no short last launch), batch x N poses per launch
+    under --gpus N (at most VR_MAX_BATCH = 512), two render streams for small launches."""
+    cli = os.path.join(ROOT, "volrend_amd", "bin", "volrend_headless")
+    subprocess.check_call(["make", "-C", ROOT, "cli"], stdout=subprocess.DEVNULL)
+    f = str(tmp_path / "poses.txt")
+    np.savetxt(f, np.concatenate([np.eye(4)] * 200))
+
+    def plan(*args):
+        r = subprocess.run([cli, "tree.npz", f, *args, "--dump_poses"], capture_output=True, text=True,
+                           timeout=60)
+        assert r.returncode == 0, r.stderr
+        w = [l for l in r.stdout.splitlines() if l.startswith("plan ")][0].split()
+        return {w[i]: int(w[i + 1]) for i in range(1, len(w), 2)}
+
+    assert plan() == dict(poses=200, launches=4, long=4, batch=50, streams=1)       # default --batch 64
+    p = plan("--batch", "32")                                                        # 29 29 29 29 28 28 28
+    assert p == dict(poses=200, launches=7, long=4, batch=29, streams=2)
+    assert p["long"] * p["batch"] + (p["launches"] - p["long"]) * (p["batch"] - 1) == 200
+    assert plan("--batch", "1") == dict(poses=200, launches=200, long=200, batch=1, streams=2)
+    assert plan("--batch", "1", "--streams", "1")["streams"] == 1
+    assert plan("--batch", "300") == dict(poses=200, launches=1, long=1, batch=200, streams=1)
+    assert plan("--max_imgs", "7", "--batch", "4") == dict(poses=7, launches=2, long=1, batch=4, streams=2)
+    # --gpus N: the launch grows with N (work per rank and launch as on one GPU), capped at 512
+    assert plan("--gpus", "2") == dict(poses=200, launches=2, long=2, batch=100, streams=1)
+    assert plan("--gpus", "8") == dict(poses=200, launches=1, long=1, batch=200, streams=1)
+    assert plan("--gpus", "8", "--batch", "8") == dict(poses=200, launches=4, long=4, batch=50, streams=1)
+    assert plan("--gpus", "8", "--batch", "500")["batch"] == 200
+
+
 REF = "/root/reference"
 
 

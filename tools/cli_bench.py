@@ -28,6 +28,35 @@ def run(args):
     return {"ms_per_frame": round(ms, 4), "fps": round(fps, 1), "process_wall_s": round(wall, 2)}
 
 
+def render_loop(npz, cfg, work):
+    """volrend::VolumeRenderer::render() called frame after frame (the interactive path: composited,
+    cleared frame, one launch per frame on the facade's two alternating frame streams), 200 frames
+    over 8 orbit cameras: tests/cpp/renderer_check.cpp in its "loop" mode."""
+    import numpy as np
+    exe = os.path.join(work, "renderer_check")
+    subprocess.check_call(["make", "-C", ROOT, "host"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                           "-I", "/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "renderer_check.cpp"),
+                           os.path.join(ROOT, "volrend_amd", "libvolrend_host.a"), "-L", os.path.join(ROOT, "volrend_amd"),
+                           "-lvolrend_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lz", "-pthread",
+                           "-Wl,-rpath," + os.path.join(ROOT, "volrend_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    spec = [f"size {cfg['width']} {cfg['height']} {cfg['focal']!r} {cfg['focal']!r}", "background_brightness 1.0",
+            "loop 200"]
+    for i in range(8):
+        a = 2.0 * np.pi * i / 8.0
+        c = np.array([4.0 * np.cos(a) * np.cos(0.5), 4.0 * np.sin(a) * np.cos(0.5), 4.0 * np.sin(0.5)])
+        b = c / np.linalg.norm(c)
+        spec.append("cam " + " ".join(repr(float(x)) for x in (*c, *b)))
+    sp = os.path.join(work, "loop_spec.txt")
+    open(sp, "w").write("\n".join(spec) + "\n")
+    r = subprocess.run([exe, npz, sp, os.path.join(work, "loop.raw")], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        return {"error": (r.stdout + r.stderr)[-400:]}
+    ms = float(re.search(r"loop_ms_per_frame ([0-9.]+)", r.stdout).group(1))
+    return {"ms_per_frame": round(ms, 4), "fps": round(1000.0 / ms, 1), "frames": 200,
+            "what": "VolumeRenderer::render() frame after frame, 800x800 of C1, composited over the cleared frame"}
+
+
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "C1"
     cfg = synth.CONFIGS[name]
@@ -56,6 +85,7 @@ def main():
     out["gpus1_rccl_self"] = run(common + ["--batch", "64", "--gpus", "1"])
     out["gpus2_shared_gpu_rehearsal"] = run(common + ["--batch", "64", "--gpus", "2", "--share_gpu"])
     out["write_png"] = run(common + ["-o", os.path.join(work, "out")])
+    out["volume_renderer_render_loop"] = render_loop(npz, cfg, work)
     out["png_files"] = len(os.listdir(os.path.join(work, "out")))
     shutil.rmtree(work, ignore_errors=True)
     print(json.dumps(out))

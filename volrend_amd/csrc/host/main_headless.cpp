@@ -160,6 +160,33 @@ void make_dirs(const std::string& path) {
     }
 }
 
+// How the pose list is cut into launches.  A launch pays one ray-chain latency of ramp-up + tail
+// whatever it carries, and under --gpus N every rank only renders 1/N of each frame: the launch
+// grows with N so that the work per rank and launch does not shrink (bench.py --gpus N does the
+// same).  The list is cut into ceil(P / batch) EQUAL launches (sizes differ by at most one pose:
+// no short last launch), the first `n_long` of them carry `batch` poses, the rest one less.
+struct LaunchPlan {
+    int batch = 1;          // poses of a long launch
+    size_t n_launches = 0;
+    size_t n_long = 0;
+    int n_streams = 1;      // render streams the launches alternate between
+};
+LaunchPlan plan_launches(size_t n_poses, int batch_arg, int n_gpus, int streams_arg) {
+    LaunchPlan p;
+    int batch = batch_arg < 1 ? 1 : batch_arg;
+    if (n_gpus > 1) batch = batch > VR_MAX_BATCH / n_gpus ? VR_MAX_BATCH : batch * n_gpus;
+    if (batch > VR_MAX_BATCH) batch = VR_MAX_BATCH;
+    if (n_poses == 0) return p;
+    p.n_launches = (n_poses + (size_t)batch - 1) / (size_t)batch;
+    p.batch = (int)((n_poses + p.n_launches - 1) / p.n_launches);
+    p.n_long = n_poses - (size_t)(p.batch - 1) * p.n_launches;
+    // A launch drains for ~0.25 ms while its longest rays finish; on a second stream the next
+    // launch starts under that tail (auto: below 48 poses per launch; at 50 the two are a tie).
+    p.n_streams = streams_arg <= 0 ? (p.batch < 48 ? 2 : 1) : (streams_arg > 2 ? 2 : streams_arg);
+    if (n_gpus >= 1) p.n_streams = 1;  // the tile shard brings its own streams
+    return p;
+}
+
 }  // namespace
 
 int main(int argc, char* argv[]) {
@@ -245,6 +272,13 @@ int main(int argc, char* argv[]) {
             read_intrins(args.str("intrin"), fx, fy);
             printf("intrin %.9g %.9g\n", fx, fy);
         }
+        size_t n_poses = trans.size();
+        if (args.as_int("max_imgs") > 0 && n_poses > (size_t)args.as_int("max_imgs"))
+            n_poses = (size_t)args.as_int("max_imgs");
+        const LaunchPlan lp = plan_launches(n_poses, args.as_int("batch"), args.as_int("gpus"),
+                                            args.as_int("streams"));
+        printf("plan poses %zu launches %zu long %zu batch %d streams %d\n", n_poses, lp.n_launches,
+               lp.n_long, lp.batch, lp.n_streams);
         return 0;
     }
     if (trans.empty()) {
@@ -287,17 +321,9 @@ int main(int argc, char* argv[]) {
         }
     }
     const int n_gpus = args.as_int("gpus");
-    int batch = args.as_int("batch");
-    if (batch < 1) batch = 1;
-    // A launch pays one ray-chain latency of ramp-up + tail whatever it carries, and under
-    // --gpus N every rank only renders 1/N of each frame: the launch grows with N so that the
-    // work per rank and launch does not shrink (bench.py --gpus N does the same).
-    if (n_gpus > 1) batch *= n_gpus;
-    if (batch > VR_MAX_BATCH) batch = VR_MAX_BATCH;
-    // equal launches: ceil(P / batch) of them, sizes differing by at most one pose
-    const size_t n_launches = (trans.size() + (size_t)batch - 1) / (size_t)batch;
-    batch = (int)((trans.size() + n_launches - 1) / n_launches);
-    const size_t n_long = trans.size() - (size_t)(batch - 1) * n_launches;  // launches of `batch` poses; the rest carry one less
+    const LaunchPlan plan = plan_launches(trans.size(), args.as_int("batch"), n_gpus, args.as_int("streams"));
+    const int batch = plan.batch;
+    const size_t n_long = plan.n_long;
     const int fp_mode = args.str("fp") == "fma" ? VR_FP_FMA : VR_FP_STRICT;
 
     const size_t frame_bytes = (size_t)width * height * 4;
@@ -353,10 +379,7 @@ int main(int argc, char* argv[]) {
     }
     // Render streams: launch k runs on stream k % n_streams and writes image set k % 2 -- with two
     // streams every stream owns one image set (the tile shard brings its own streams).
-    int n_streams = args.as_int("streams");
-    if (n_streams <= 0) n_streams = batch < 48 ? 2 : 1;
-    if (n_streams > 2) n_streams = 2;
-    if (shard) n_streams = 1;
+    const int n_streams = shard ? 1 : plan.n_streams;
     hipStream_t streams[2] = {nullptr, nullptr};
     if (shard) streams[0] = static_cast<hipStream_t>(shard->out_stream());
     else
