@@ -33,7 +33,8 @@ def render_loop(npz, cfg, work):
     cleared frame, one launch per frame on the facade's two alternating frame streams), 200 frames
     over 8 orbit cameras: tests/cpp/renderer_check.cpp in its "loop" mode."""
     import numpy as np
-    exe = os.path.join(work, "renderer_check")
+    import tempfile
+    exe = os.path.join(tempfile.mkdtemp(prefix="vr_loop_", dir="/tmp"), "renderer_check")  # (/dev/shm is noexec)
     subprocess.check_call(["make", "-C", ROOT, "host"], stdout=subprocess.DEVNULL)
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
                            "-I", "/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "renderer_check.cpp"),
