@@ -402,11 +402,11 @@ int main(int argc, char* argv[]) {
         }
     };
 
-    // The launch slots' ray buffers are sized BEFORE the clock starts (two slots: one per render
+    // The launch slots' ray buffers are sized BEFORE the clock starts (one slot per render
     // stream; 76 bytes per ray of a launch -- 2.4 GB at 50 poses of 800 x 800): left to the first
     // launches, the allocations would sit inside the timed loop, as the reference's cudaArray
     // would if it were created behind cudaEventRecord(start) (main_headless.cpp:187-203).
-    if (!shard && vr_reserve(tree.device, width, height, batch) != VR_OK) {
+    if (!shard && vr_reserve_tiles(tree.device, width, height, batch, 0, 0, 1, n_streams) != VR_OK) {
         fprintf(stderr, "ERROR: %s\n", vr_last_error());
         return 1;
     }
