@@ -45,8 +45,7 @@ struct VolumeRenderer::Impl {
     // next launch's start under the previous launch's tail (a lone frame drains for ~0.3 ms
     // while its longest rays finish: one frame per launch runs at 0.40 instead of 0.58 ms on
     // two alternating streams, profiles/r05_stream_overlap.jsonl).
-    hipStream_t streams[2] = {nullptr, nullptr};
-    hipStream_t& stream = streams[0];  // (the first one stands for "streams exist")
+    hipStream_t streams[2] = {nullptr, nullptr};  // (both or none)
     uint8_t* rgba[2] = {nullptr, nullptr};
     float* depth[2] = {nullptr, nullptr};
     int buf_index = 0, last = -1;
@@ -69,7 +68,7 @@ struct VolumeRenderer::Impl {
     }
     void start() {  // cuda_renderer.cpp:59-81 without the GL objects
         const int want = target_device();
-        if (stream && device != want) {
+        if (streams[0] && device != want) {
             OnDevice on(device);
             sync_all();
             release();
@@ -78,7 +77,7 @@ struct VolumeRenderer::Impl {
                 st = nullptr;
             }
         }
-        if (!stream) {
+        if (!streams[0]) {
             OnDevice on(want);
             for (auto& st : streams) hip_check(hipStreamCreate(&st), "hipStreamCreate");
             device = want;
