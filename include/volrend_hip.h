@@ -276,6 +276,13 @@ int vr_sched_stats(vr_tree_t tree, uint64_t out[8], int reset);
  * are synchronous (device-wide).  Production launches never see the bitmaps. */
 int vr_touch_enable(vr_tree_t tree, int enable);
 int vr_touch_count(vr_tree_t tree, uint64_t out[4], int reset);
+/* The bitmap of array `which` (0 records, 1 child words, 2 top grid, 3 bricks) itself, copied to
+ * host memory: bit b of word w = granule 32 w + b of the array was touched; *granule_bytes (if
+ * not NULL) receives the bytes one bit stands for (128; layout studies build the library with
+ * a finer grain for the records).  Copies min(n_words, size of the bitmap) words and returns
+ * the size of the bitmap in *bitmap_words (if not NULL).  Synchronous. */
+int vr_touch_read(vr_tree_t tree, int which, uint32_t* host_words, uint64_t n_words,
+                  uint64_t* bitmap_words, uint64_t* granule_bytes);
 /* gathered = world consecutive COMPACT buffers (rank-major), all device memory
  * on the current device.  Writes the W x H frame. */
 int vr_assemble_tiles(void* frame_rgba, int64_t pitch, const void* gathered, int width,

@@ -46,6 +46,11 @@ def test_touch_counts_are_a_set_measure(torch_cuda):
     t.touch_enable(True)
     img_a, cnt_a = _render_counted(torch, api, t, tr_a, w, h, f)
     a = t.touch_count(reset=False)
+    # the bitmaps themselves (vr_touch_read): one bit per 128-byte line, as many set as counted
+    for which, key in enumerate(("leaves", "nodes", "top", "bricks")):
+        bm, gran = t.touch_read(which)
+        assert gran == 128
+        assert int(np.unpackbits(bm.view(np.uint8)).sum()) == a[key], key
     _render_counted(torch, api, t, tr_a, w, h, f)        # the same frame again: same set
     assert t.touch_count(reset=True) == a
     assert t.touch_count(reset=False) == dict(leaves=0, nodes=0, top=0, bricks=0)  # reset worked

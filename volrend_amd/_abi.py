@@ -101,6 +101,8 @@ PROTOTYPES = {
     "vr_sched_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 8), C.c_int]),
     "vr_touch_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "vr_touch_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 4), C.c_int]),
+    "vr_touch_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                C.POINTER(C.c_uint64)]),
     "vr_assemble_tiles": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_void_p]),
     "vr_assemble_tiles_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,

@@ -332,6 +332,16 @@ class N3Tree:
         _abi.check(_abi.lib().vr_touch_count(self.handle, C.byref(out), 1 if reset else 0))
         return dict(zip(("leaves", "nodes", "top", "bricks"), [int(v) for v in out]))
 
+    def touch_read(self, which: int):
+        """The distinct-line bitmap of array ``which`` (0 records, 1 child words, 2 top grid,
+        3 bricks) as (uint32 numpy array, bytes per bit) -- vr_touch_read."""
+        words, gran = C.c_uint64(0), C.c_uint64(0)
+        _abi.check(_abi.lib().vr_touch_read(self.handle, int(which), None, 0, C.byref(words), C.byref(gran)))
+        out = np.zeros(int(words.value), dtype=np.uint32)
+        if out.size:
+            _abi.check(_abi.lib().vr_touch_read(self.handle, int(which), out.ctypes.data, out.size, None, None))
+        return out, int(gran.value)
+
     def reserve(self, width: int, height: int, n_frames: int, shard: "TileShard | None" = None,
                 n_slots: int = 2) -> None:
         """Pre-allocate the per-launch ray buffers (vr_reserve / vr_reserve_tiles): no later

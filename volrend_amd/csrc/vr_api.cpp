@@ -1189,8 +1189,12 @@ int vr_sched_stats(vr_tree_t t, uint64_t out[8], int reset) {
     return VR_OK;
 }
 
-static size_t touch_words(uint64_t array_bytes) {  // one bit per 128-byte line
-    return (size_t)(((array_bytes + 127) / 128 + 31) / 32);
+static uint64_t touch_granule(int which) {  // bytes one bit of the bitmap stands for
+    return which == 0 ? (1ull << VR_TOUCH_LEAF_SHIFT) : 128ull;
+}
+static size_t touch_words(uint64_t array_bytes, int which) {  // one bit per 128-byte line
+    const uint64_t g = touch_granule(which);
+    return (size_t)(((array_bytes + g - 1) / g + 31) / 32);
 }
 
 int vr_touch_enable(vr_tree_t t, int enable) {
@@ -1203,7 +1207,7 @@ int vr_touch_enable(vr_tree_t t, int enable) {
             HIP_TRY(hipFree(t->touch[i]));
             t->touch[i] = nullptr;
         }
-        const size_t words = touch_words(t->array_bytes[i]);
+        const size_t words = touch_words(t->array_bytes[i], i);
         if (enable && words) {
             HIP_TRY(hipMalloc((void**)&t->touch[i], words * sizeof(uint32_t)));
             HIP_TRY(hipMemset(t->touch[i], 0, words * sizeof(uint32_t)));
@@ -1222,11 +1226,29 @@ int vr_touch_count(vr_tree_t t, uint64_t out[4], int reset) {
     HIP_TRY(hipMemset(t->touch_out, 0, 4 * sizeof(unsigned long long)));
     for (int i = 0; i < 4; ++i) {
         if (!t->touch[i]) continue;
-        const size_t words = touch_words(t->array_bytes[i]);
+        const size_t words = touch_words(t->array_bytes[i], i);
         HIP_TRY(vr::launch_popcount(t->touch[i], words, t->touch_out + i, nullptr));
         if (reset) HIP_TRY(hipMemsetAsync(t->touch[i], 0, words * sizeof(uint32_t), nullptr));
     }
     HIP_TRY(hipMemcpy(out, t->touch_out, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return VR_OK;
+}
+
+int vr_touch_read(vr_tree_t t, int which, uint32_t* host_words, uint64_t n_words,
+                  uint64_t* bitmap_words, uint64_t* granule_bytes) {
+    if (!t || which < 0 || which > 3) return fail(VR_ERR_INVALID_ARGUMENT, "tree / array index");
+    if (!t->touch_out) return fail(VR_ERR_INVALID_ARGUMENT, "vr_touch_enable(tree, 1) first");
+    DeviceGuard guard(t->device);
+    std::lock_guard<std::mutex> lock(t->launch_mutex);
+    // (an array the tree does not have -- no bricks, say -- has an empty bitmap)
+    const uint64_t words = t->touch[which] ? touch_words(t->array_bytes[which], which) : 0;
+    if (bitmap_words) *bitmap_words = words;
+    if (granule_bytes) *granule_bytes = touch_granule(which);
+    const uint64_t n = n_words < words ? n_words : words;
+    if (host_words && n) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(host_words, t->touch[which], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
     return VR_OK;
 }
 

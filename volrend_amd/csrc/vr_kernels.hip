@@ -189,7 +189,8 @@ enum { TOUCH_LEAVES = 0, TOUCH_NODES = 1, TOUCH_TOP = 2, TOUCH_BRICKS = 3 };
 __device__ __forceinline__ void touch(const KParams& p, int which, uint64_t off, uint32_t bytes) {
     uint32_t* bm = p.touch[which];
     if (!bm) return;
-    const uint64_t l0 = off >> 7, l1 = (off + bytes - 1) >> 7;
+    const int sh = which == TOUCH_LEAVES ? VR_TOUCH_LEAF_SHIFT : 7;
+    const uint64_t l0 = off >> sh, l1 = (off + bytes - 1) >> sh;
     atomicOr(&bm[l0 >> 5], 1u << (l0 & 31u));
     if (l1 != l0) atomicOr(&bm[l1 >> 5], 1u << (l1 & 31u));
 }
