@@ -1266,9 +1266,10 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         // wave has marched p.max_iter rounds without retiring a single ray, whatever is still
         // marching is cut and reported (sticky status bit 0: the host layers fail loudly on it;
         // WHICH rays share a wave depends on the scheduling knobs, so the pixels of a launch that
-        // tripped the guard are not tuning-independent -- they are wrong either way).  Wave-uniform and checked once per pass through here
-        // (<= march_max rounds), so that a march round carries nothing of it (five vector and
-        // four scalar instructions per round until round 3; -2 % frame time, profiles/r04_*).
+        // tripped the guard are not tuning-independent -- they are wrong either way).  Wave-uniform
+        // and checked once per pass through here (<= march_max rounds), so that a march round
+        // carries nothing of it (five vector and four scalar instructions per round until round 3;
+        // -2 % frame time, profiles/r04_*).
         if (rounds - progress_round >= (uint32_t)p.max_iter) {
             if (ray.t < ray.tmax) {
                 ray.t = ray.tmax;
