@@ -365,16 +365,21 @@ int main(int argc, char* argv[]) {
     std::unique_ptr<EncodePool> pool;
     hipStream_t copy_stream = nullptr;
     hipEvent_t rendered[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+    // one event behind the copy of every frame of a set: a frame is handed to the encoders as soon
+    // as ITS copy has landed, so that the encoding of the last launch runs under its own copies
+    std::vector<hipEvent_t> frame_copied[2];
     if (!out_dir.empty()) {
         make_dirs(out_dir);
         for (auto& hs : host_sets) HIP_OK(hipHostMalloc((void**)&hs, frame_bytes * batch));
         unsigned nt = std::thread::hardware_concurrency();
-        nt = nt == 0 ? 4 : (nt > 32 ? 32 : nt);
+        nt = nt == 0 ? 4 : (nt > 64 ? 64 : nt);
         pool.reset(new EncodePool(nt));
         HIP_OK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
             HIP_OK(hipEventCreateWithFlags(&rendered[i], hipEventDisableTiming));
             HIP_OK(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+            frame_copied[i].resize((size_t)batch);
+            for (auto& e : frame_copied[i]) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
     }
     // Render streams: launch k runs on stream k % n_streams and writes image set k % 2 -- with two
@@ -392,8 +397,8 @@ int main(int argc, char* argv[]) {
     // Frame egress of launch `seq` (frames [first, first + n)): called one launch late, so the
     // host waits for the copies of launch k - 1 while the GPU renders launch k.
     auto submit_encodes = [&](int set, size_t first, int n) {
-        HIP_OK(hipEventSynchronize(copied[set]));
         for (int i = 0; i < n; ++i) {
+            HIP_OK(hipEventSynchronize(frame_copied[set][(size_t)i]));
             const std::string fpath = out_dir + "/" + basenames[first + i] + ".png";
             const uint8_t* src = host_sets[set] + frame_bytes * i;
             pool->submit(set, [fpath, src, width, height] {
@@ -456,10 +461,15 @@ int main(int argc, char* argv[]) {
             HIP_OK(hipEventRecord(rendered[set], stream));
             pool->wait(set);  // the encoders (launch seq - 2) are done with this host buffer set
             HIP_OK(hipStreamWaitEvent(copy_stream, rendered[set], 0));
-            // the n frames of a launch are contiguous: one copy
-            if (vr_read_back(host_sets[set], dev_frames, 0, width, height * n, copy_stream) != VR_OK) {
-                fprintf(stderr, "ERROR: %s\n", vr_last_error());
-                return 1;
+            // frame by frame (2.56 MB at 800 x 800: large enough for the copy engine), an event
+            // behind each
+            for (int i = 0; i < n; ++i) {
+                if (vr_read_back(host_sets[set] + frame_bytes * i, dev_frames + frame_bytes * i, 0, width,
+                                 height, copy_stream) != VR_OK) {
+                    fprintf(stderr, "ERROR: %s\n", vr_last_error());
+                    return 1;
+                }
+                HIP_OK(hipEventRecord(frame_copied[set][(size_t)i], copy_stream));
             }
             HIP_OK(hipEventRecord(copied[set], copy_stream));
             if (prev_n > 0) submit_encodes(set ^ 1, prev_first, prev_n);
@@ -503,6 +513,7 @@ int main(int argc, char* argv[]) {
     for (int i = 0; i < 2; ++i) {
         if (rendered[i]) HIP_OK(hipEventDestroy(rendered[i]));
         if (copied[i]) HIP_OK(hipEventDestroy(copied[i]));
+        for (auto e : frame_copied[i]) HIP_OK(hipEventDestroy(e));
     }
     if (copy_stream) HIP_OK(hipStreamDestroy(copy_stream));
     if (!shard) {
