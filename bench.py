@@ -259,6 +259,39 @@ def rtfrag_baseline(timeout_s=240):
             "psnr_vs_oracle_db": r["psnr_rt_frag_vs_oracle_db"]}
 
 
+def self_launch_command(argv, gpus: int, port: int | None = None):
+    """The command `python bench.py --gpus N ...` turns itself into when it is started WITHOUT a
+    launcher (no WORLD_SIZE in the environment): the documented torch.distributed.run form, one
+    process per GPU, same argv, a free local port."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(argv, gpus: int) -> int:
+    """Runs self_launch_command and relays rank 0's ONE JSON line (the children's stdout carries
+    nothing else; their stderr passes through).  Returns the launcher's exit code."""
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = self_launch_command(argv, gpus)
+    log("[bench] no launcher in the environment: " + " ".join(cmd))
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    elif p.returncode == 0:
+        log("[bench] the ranks ended without a result line")
+        return 1
+    return p.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,10 +322,11 @@ def main():
                          "timed region finds the GPU in the power state of a running render loop "
                          "(after ~5 ms of idling an MI355X needs ~30 ms of work to be back at full "
                          "clocks: profiles/r04_lone_launch_probe.jsonl); 0 = none")
-    ap.add_argument("--live-traffic", type=int, default=-1,
-                    help="measure the L2<->fabric traffic of THIS run's launch shape with two rocprofv3 "
-                         "--pmc passes after the timed region (1), or report the committed, hash-verified "
-                         "measurement only (0); -1 = live when rocprofv3 is on the PATH, one GPU, config C1")
+    ap.add_argument("--live-traffic", type=int, default=0,
+                    help="0 (default): roofline.traffic is the committed, hash-verified rocprofv3 measurement "
+                         "of these kernel sources (profiles/r*_traffic_*.json); 1: measure the L2<->fabric "
+                         "traffic of THIS run's launch shape with two rocprofv3 --pmc passes of a child "
+                         "process after the timed region (tools/job_final.sh opts in)")
     ap.add_argument("--cold", type=int, default=1,
                     help="after the repeats, time the identical K-step region once more behind 50 ms of "
                          "idling (ms_per_step_cold: a launch out of an idle GPU, the condition rounds 1-3 "
@@ -301,6 +335,10 @@ def main():
                     help="after the timed region, the identical K-step region is run this many more "
                          "times (not part of value / ms_per_step): the line's own noise floor")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher (one process per GPU), relay the line
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
 
     # stdout carries exactly ONE JSON line: everything else that writes to fd 1 (RCCL prints
     # its version banner there) is sent to stderr; the JSON goes to the saved descriptor.
@@ -317,9 +355,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if args.gpus != world and rank == 0:  # the launcher decides; n_gpus in the line is what really ran
+        log(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): "
+            f"running with {world}")
     # VOLREND_BENCH_SHARE_GPU=1 (rehearsal only, never a measurement): all ranks use cuda:0 and
     # the collectives go through gloo with host staging -- lets the N > 1 code path (shards,
     # pipeline, assembly, self-check, rank-0 JSON) run on a one-GPU box, where RCCL refuses
@@ -636,7 +674,7 @@ def main():
     traffic, traffic_src, traffic_extrapolated = None, None, None
     launch_sizes = [min(B, K - j * B) for j in range(n_launch)]
     live, committed_note = None, None
-    want_live = args.live_traffic == 1 or (args.live_traffic < 0 and args.config == "C1")
+    want_live = args.live_traffic == 1
     if world == 1 and rank == 0 and want_live and not args.readback and n_streams == 1:
         # the child processes of the live passes upload the tree themselves: this process is done
         # with the GPU, so its copy (and the frame sets) go first

@@ -60,9 +60,16 @@ struct VolumeRenderer {
     // ---- in place of the GL framebuffer ----
     // Device images every render() starts from (both optional, camera.width x camera.height,
     // dense rows): what upstream's meshes leave in the colour and the R32F depth attachment.
-    // The buffers stay the caller's; they are copied on render()'s stream.  They belong to the
-    // frame size of the moment: after resize() hand them in again (render() refuses a stale pair).
-    void set_underlay(const void* rgba8_dev, const float* depth_dev);
+    // The buffers stay the caller's; every render() copies them on the stream of the frame it
+    // writes (the two frames alternate between two streams: next_stream()).  Ordering against the
+    // work that PRODUCES them: pass the stream (hipStream_t) it runs on as `producer_stream` and
+    // render() (a) makes its copies wait for everything enqueued there so far and (b) makes that
+    // stream wait for the copies, so the producer may overwrite the images for the next frame
+    // right after render() returns.  Without a producer stream the images must be complete (and
+    // stay untouched) on the host's clock: synchronise before render(), and after it before
+    // writing them again.  They belong to the frame size of the moment: after resize() hand
+    // them in again (render() refuses a stale pair).
+    void set_underlay(const void* rgba8_dev, const float* depth_dev, void* producer_stream = nullptr);
     // The frame the last render() wrote (device memory, RGBA8, width * 4 bytes per row)
     const uint8_t* frame() const;
     // Waits for the last render() and copies its frame to host memory (width * height * 4 bytes).
@@ -73,6 +80,9 @@ struct VolumeRenderer {
     // idle.  The two frames alternate between two streams of their own, so that a render() issued
     // before the previous frame has been consumed starts under that launch's tail.
     void* stream() const;
+    // The stream the NEXT render() will use (created on first use): for callers that order their
+    // own device work against it.
+    void* next_stream();
 
    private:
     struct Impl;

@@ -31,5 +31,11 @@ void launch_renderer_batch(const N3Tree& tree, const Camera& cam,
 // copy of a frame -- to get the reference's loud failure (src/cuda/common.cu:8-21 prints and
 // exits; this throws std::runtime_error and clears the word).  Synchronous.
 void check_render_status(const N3Tree& tree);
+// The same on a stream the caller is about to wait for anyway (vr_tree_status_on): enqueues the
+// read of the word (and its clear) on `stream`, synchronises THAT stream only and throws as above.  Other streams
+// that render the same tree are not waited for (check_render_status copies on the legacy stream,
+// which waits for every blocking stream of the device); the word is the tree's, so bits set by
+// their launches show up in whichever check comes first.
+void check_render_status(const N3Tree& tree, void* stream);
 
 }  // namespace volrend

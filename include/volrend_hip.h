@@ -124,7 +124,22 @@ typedef struct VrTreeInfo {
     int32_t device;
     uint64_t device_bytes;   /* total HBM held for this tree */
     uint64_t leaf_stride;    /* bytes between SH records in the device layout */
+    int32_t query_mode;      /* VR_QUERY_LOOKUP / VR_QUERY_DESCENT: how a sample finds its leaf (below) */
+    int32_t top_levels;      /* lookup structure built at upload: 2^top_levels cells per axis (0 = none) */
+    int32_t brick_levels;    /* 2^brick_levels entries per axis of a brick (0 = no bricks) */
+    int32_t brick_blocked;   /* bricks stored in 4 x 4 x 2 line blocks */
 } VrTreeInfo;
+
+/* How the kernels resolve query_single_from_root (n3tree_query.hpp:13-48) for a tree:
+ *   VR_QUERY_LOOKUP  : N == 2, every leaf within 24 levels and fewer than 2^27 nodes -- integer
+ *                      digits of the binary32 coordinate index a top grid + bricks (bit-identical);
+ *   VR_QUERY_DESCENT : anything else the format allows (N != 2, deeper trees, larger arrays) -- the
+ *                      literal float descent of the reference, level by level.
+ * vr_query_mode_for is the rule vr_tree_upload applies (pure host arithmetic; max_depth as in
+ * VrTreeInfo: the deepest leaf reads max_depth + 1 child words). */
+#define VR_QUERY_LOOKUP 0
+#define VR_QUERY_DESCENT 1
+int vr_query_mode_for(int N, int max_depth, int64_t capacity);
 
 /* CameraSpec: column-major 4x3 camera-to-world (right, up, back, centre) */
 typedef struct VrCamera {
@@ -243,8 +258,8 @@ int vr_reserve(vr_tree_t tree, int width, int height, int n_frames);
 int vr_reserve_tiles(vr_tree_t tree, int width, int height, int n_frames, int tile_w, int tile_h,
                      int world, int n_slots);
 /* Sticky device status word of the tree's launches: bit 0 = some ray hit the sample guard (a
- * wave marched 2^22 rounds -- tuning key "max_iter" -- without retiring a single ray; the
- * reference would still be looping).  Synchronous; reset != 0 clears it.
+ * wave marched 2^22 rounds -- tuning key "max_iter" -- since the last retire / refill pass in
+ * which one of its rays retired; the reference would still be looping).  Synchronous; reset != 0 clears it.
  * vr_render* refuses step_size <= 0 / NaN (VR_ERR_INVALID_ARGUMENT), where the reference
  * hangs, so the bit only ever fires on pathological step_size / scene combinations.  A launch
  * that set it has WRONG pixels (the wave's marching rays were cut; which rays share a wave
@@ -254,12 +269,20 @@ int vr_reserve_tiles(vr_tree_t tree, int width, int height, int n_frames, int ti
  * and bench.py do, and fail loudly (the reference's abort-on-error convention,
  * src/cuda/common.cu:8-21). */
 int vr_tree_status(vr_tree_t tree, uint32_t* status, int reset);
-/* Scheduling / layout knobs ("march_max", "refill_min", "waves_per_cu", "records_nt",
- * "top_levels", "brick_levels", ...); results never depend on them ("max_iter", the sample
+/* The same word read ON A STREAM: the copy (into pinned memory of the library) and, with
+ * reset != 0, the clear are enqueued on `stream`; then THAT stream is waited for and the value
+ * returned.  No other stream is waited for -- vr_tree_status copies on the legacy stream and so
+ * waits for every blocking stream of the device: a render loop on two alternating streams that
+ * checks frame k would wait for frame k + 1 as well.  The word is the TREE's: launches of the same
+ * tree on other streams set the same bits, and whichever check comes first reports them. */
+int vr_tree_status_on(vr_tree_t tree, uint32_t* status, int reset, void* stream);
+/* Scheduling / layout knobs ("march_max", "refill_min", "waves_per_cu", "records_nt", "raygen_waves",
+ * "top_levels", "brick_levels", "brick_blocked", ...); results never depend on them ("max_iter", the sample
  * guard above, is the exception by design: a launch that trips it says so in vr_tree_status).  Every tree carries its own
  * copy, taken at upload (or from the source of a clone) from the process defaults:
  *   vr_set_tuning       changes the DEFAULTS of trees uploaded afterwards (serialised);
- *   vr_tree_set_tuning  changes one tree (not the upload-time keys top_levels / brick_levels);
+ *   vr_tree_set_tuning  changes one tree (not the upload-time keys top_levels / brick_levels /
+ *                       brick_blocked: VR_ERR_INVALID_ARGUMENT);
  *                       takes effect with that tree's next launch, any thread. */
 int vr_set_tuning(const char* key, int value);
 int vr_tree_set_tuning(vr_tree_t tree, const char* key, int value);

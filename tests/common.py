@@ -140,3 +140,67 @@ def random_configuration(seed):
               render_depth=int(rng.random() < 0.2))
     ndc = (float(w), float(h), float(focal)) if rng.random() < 0.25 else None
     return tree, tr, w, h, focal, ndc, kw, (fmt, bd)
+
+
+def deep_chain_tree_n2(depth=28, basis_dim=4, fmt="SH", seed=0, target=(3.1e-4, 5.3e-4, 4.2e-4)):
+    """An N = 2 tree that is a CHAIN towards `target`: at every level the child that contains the
+    target is refined again (and one more child of the node into a node of leaves), `depth` levels
+    deep -- a few dozen nodes with leaves of every depth 1..depth.  Deeper than 24 levels the
+    integer lookup of the kernels (exact digits of a binary32 coordinate) does not apply and
+    vr_tree_upload routes the tree to the literal float descent, which the reference runs for
+    every tree (n3tree_query.hpp:22-47).  offset 0 / scale 1: tree coordinates = world
+    coordinates, so that a camera placed AT the target (coordinates ~1e-4: binary32 resolves
+    2^-36 there) starts every ray inside the deepest leaf.  Returns (tree, target as float32)."""
+    from volrend_amd import synth
+    rng = np.random.default_rng(seed)
+    T = np.asarray(target, dtype=np.float32)
+    data_dim = 4 if fmt == "RGBA" else 3 * basis_dim + 1
+    child_rows, level_of = [np.zeros(8, np.int64)], [0]   # absolute child ids, 0 = leaf
+    x = T.astype(np.float64).copy()
+    node = 0
+    for lvl in range(depth - 1):
+        x *= 2.0
+        k = np.floor(x).astype(np.int64)
+        x -= k
+        slot = int(k[0] * 4 + k[1] * 2 + k[2])            # x is the most significant digit
+        nxt = len(child_rows)
+        child_rows.append(np.zeros(8, np.int64))
+        level_of.append(lvl + 1)
+        child_rows[node][slot] = nxt
+        other = int((slot + 1 + rng.integers(7)) % 8)     # one sibling becomes a node of leaves
+        side = len(child_rows)
+        child_rows.append(np.zeros(8, np.int64))
+        level_of.append(lvl + 1)
+        child_rows[node][other] = side
+        node = nxt
+    cap = len(child_rows)
+    ids = np.stack(child_rows)
+    child = np.where(ids != 0, ids - np.arange(cap)[:, None], 0).astype(np.int32)
+    data = np.zeros((cap, 8, data_dim), dtype=np.float32)
+    data[..., :-1] = rng.standard_normal((cap, 8, data_dim - 1)) * 0.6
+    if fmt == "RGBA":
+        data[..., :3] = rng.uniform(0.05, 0.95, size=(cap, 8, 3))
+    lvl = np.asarray(level_of)[:, None]
+    occ = (rng.random((cap, 8)) < 0.6) & (child == 0)
+    # steps near the target are ~1e-8 long: deep leaves get large densities so that they still weigh in
+    sig = np.where(lvl >= 14, np.exp(rng.uniform(np.log(2e3), np.log(6e4), size=(cap, 8))),
+                   np.exp(rng.uniform(np.log(2.0), np.log(200.0), size=(cap, 8))))
+    data[..., -1] = np.where(occ, sig, 0)
+    data[child != 0] = 0
+    name = "RGBA" if fmt == "RGBA" else f"{fmt}{basis_dim}"
+    tree = synth.SynthTree(child.reshape(cap, 2, 2, 2), data.astype(np.float16).reshape(cap, 2, 2, 2, data_dim),
+                           np.zeros(3, np.float32), np.ones(3, np.float32), name, None, depth)
+    return tree, T
+
+
+def camera_at(position, look_at=(0.5, 0.5, 0.5), size=40, focal=28.0):
+    """12-float transform (columns right, up, back, centre) of a camera AT `position` (float32,
+    kept bit for bit) looking at `look_at`."""
+    c = np.asarray(position, dtype=np.float32)
+    back = c.astype(np.float64) - np.asarray(look_at, np.float64)
+    back /= np.linalg.norm(back)
+    right = np.cross([0.0, 0.0, 1.0], back)
+    right /= np.linalg.norm(right)
+    up = np.cross(back, right)
+    tr = np.concatenate([right, up, back]).astype(np.float32)
+    return np.concatenate([tr, c]).astype(np.float32), size, size, focal

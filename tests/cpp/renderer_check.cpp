@@ -6,7 +6,9 @@
 //   renderer_check <tree.npz> <spec.txt> <out.raw>
 // spec: "size W H FX FY", "background_brightness b", "step_size s", "burst n" (render() n times per camera),
 //       "loop n" (afterwards: n render() calls back to back, timed -> "loop_ms_per_frame x"),
-//       "underlay <rgba.raw> <depth.raw>" (optional),
+//       "underlay <rgba.raw> <depth.raw>" (optional), "underlay_stream 1" (the underlay is PRODUCED on a stream
+//       of the caller's right before every render() and overwritten with junk right after it, no host
+//       synchronisation in between: set_underlay's producer_stream must order both),
 //       one "cam cx cy cz bx by bz" per frame (camera centre and v_back; v_world_up stays +z).
 // stdout: one "transform f0 .. f11" line per frame (what Camera::_update made of the vectors)
 //         and "basis_minmax a b backend NAME".
@@ -16,6 +18,7 @@
 #include <cstdio>
 #include <fstream>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -34,7 +37,7 @@ int main(int argc, char* argv[]) {
         VolumeRenderer r;
         if (r.frame() != nullptr) return 6;  // nothing rendered yet
         std::ifstream spec(argv[2]);
-        int w = 0, h = 0, burst = 1, loop = 0;
+        int w = 0, h = 0, burst = 1, loop = 0, under_stream = 0;
         std::string under_rgba, under_depth;
         std::vector<std::vector<float>> cams;
         for (std::string line; std::getline(spec, line);) {
@@ -47,6 +50,7 @@ int main(int argc, char* argv[]) {
             else if (key == "burst") is >> burst;
             else if (key == "loop") is >> loop;
             else if (key == "underlay") is >> under_rgba >> under_depth;
+            else if (key == "underlay_stream") is >> under_stream;
             else if (key == "cam") {
                 std::vector<float> c(6);
                 for (float& v : c) is >> v;
@@ -57,22 +61,48 @@ int main(int argc, char* argv[]) {
         if (r.camera.width != w || r.camera.height != h) return 7;
         r.options.basis_minmax[1] = 24;
         r.set(tree);  // must narrow basis_minmax to the tree's basis (cuda_renderer.cpp:176-177)
-        void *d_rgba = nullptr, *d_depth = nullptr;
+        void *d_rgba = nullptr, *d_depth = nullptr, *d_true_rgba = nullptr, *d_true_depth = nullptr;
+        hipStream_t producer = nullptr;
+        const size_t img_bytes = (size_t)w * h * 4;
         if (!under_rgba.empty()) {
             const std::vector<char> a = slurp(under_rgba), b = slurp(under_depth);
-            if (a.size() != (size_t)w * h * 4 || b.size() != (size_t)w * h * 4) return 8;
+            if (a.size() != img_bytes || b.size() != img_bytes) return 8;
             if (hipMalloc(&d_rgba, a.size()) != hipSuccess || hipMalloc(&d_depth, b.size()) != hipSuccess) return 4;
-            if (hipMemcpy(d_rgba, a.data(), a.size(), hipMemcpyHostToDevice) != hipSuccess) return 4;
-            if (hipMemcpy(d_depth, b.data(), b.size(), hipMemcpyHostToDevice) != hipSuccess) return 4;
-            r.set_underlay(d_rgba, (const float*)d_depth);
+            if (under_stream) {
+                // the images a mesh pass would render: kept aside, copied into the underlay buffers
+                // ON THE PRODUCER STREAM before every render() and trashed there right after it
+                if (hipStreamCreate(&producer) != hipSuccess) return 4;
+                if (hipMalloc(&d_true_rgba, a.size()) != hipSuccess || hipMalloc(&d_true_depth, b.size()) != hipSuccess) return 4;
+                if (hipMemcpy(d_true_rgba, a.data(), a.size(), hipMemcpyHostToDevice) != hipSuccess) return 4;
+                if (hipMemcpy(d_true_depth, b.data(), b.size(), hipMemcpyHostToDevice) != hipSuccess) return 4;
+                if (hipMemset(d_rgba, 0x5A, img_bytes) != hipSuccess || hipMemset(d_depth, 0, img_bytes) != hipSuccess) return 4;
+                r.set_underlay(d_rgba, (const float*)d_depth, producer);
+                if (r.next_stream() == nullptr) return 9;
+            } else {
+                if (hipMemcpy(d_rgba, a.data(), a.size(), hipMemcpyHostToDevice) != hipSuccess) return 4;
+                if (hipMemcpy(d_depth, b.data(), b.size(), hipMemcpyHostToDevice) != hipSuccess) return 4;
+                r.set_underlay(d_rgba, (const float*)d_depth);
+            }
         }
+        auto render_once = [&]() {
+            if (producer) {
+                if (r.next_stream() == r.stream() && r.frame() != nullptr) throw std::runtime_error("frames do not alternate streams");
+                (void)hipMemcpyAsync(d_rgba, d_true_rgba, img_bytes, hipMemcpyDeviceToDevice, producer);
+                (void)hipMemcpyAsync(d_depth, d_true_depth, img_bytes, hipMemcpyDeviceToDevice, producer);
+            }
+            r.render();
+            if (producer) {  // junk: a depth of 0 would end every ray at once
+                (void)hipMemsetAsync(d_rgba, 0x5A, img_bytes, producer);
+                (void)hipMemsetAsync(d_depth, 0, img_bytes, producer);
+            }
+        };
         std::vector<uint8_t> host((size_t)w * h * 4 * (cams.size() + 1));
         for (size_t i = 0; i < cams.size(); ++i) {
             r.camera.center = glm::vec3(cams[i][0], cams[i][1], cams[i][2]);
             r.camera.v_back = glm::vec3(cams[i][3], cams[i][4], cams[i][5]);
             // burst > 1: render() again before the previous frame is consumed -- the two frames
             // alternate between two streams, consecutive launches overlap; the LAST frame is read
-            for (int b = 0; b < burst; ++b) r.render();
+            for (int b = 0; b < burst; ++b) render_once();
             r.read_frame(host.data() + (size_t)w * h * 4 * i);
             const float* t = glm::value_ptr(r.camera.transform);
             printf("transform");
@@ -96,15 +126,17 @@ int main(int argc, char* argv[]) {
         }
         // without a tree render() leaves the cleared frame / the underlay (cuda_renderer.cpp:114)
         r.clear();
-        r.render();
+        render_once();
         r.read_frame(host.data() + (size_t)w * h * 4 * cams.size());
         FILE* fp = fopen(argv[3], "wb");
         if (!fp || fwrite(host.data(), 1, host.size(), fp) != host.size()) return 5;
         fclose(fp);
         printf("basis_minmax %d %d backend %s\n", r.options.basis_minmax[0], r.options.basis_minmax[1],
                r.get_backend());
-        if (d_rgba) (void)hipFree(d_rgba);
-        if (d_depth) (void)hipFree(d_depth);
+        (void)hipDeviceSynchronize();
+        for (void* q : {d_rgba, d_depth, d_true_rgba, d_true_depth})
+            if (q) (void)hipFree(q);
+        if (producer) (void)hipStreamDestroy(producer);
     } catch (const std::exception& e) {
         printf("EXCEPTION %s\n", e.what());
         return 3;

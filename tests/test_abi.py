@@ -156,3 +156,21 @@ def test_product_never_touches_the_oracle():
     makefile = open(os.path.join(root, "Makefile")).read()
     lib_rules = makefile.split("oracle:")[0]  # everything before the oracle target
     assert "vr_oracle" not in lib_rules
+
+
+def test_query_mode_rule_is_arithmetic():
+    """Which trees take the integer lookup and which the reference's literal float descent
+    (include/volrend_hip.h VR_QUERY_*): N == 2, leaves within 24 levels, fewer than 2^27 nodes
+    (32-bit byte offsets into the node words).  Pure host arithmetic -- the 2^27-node boundary is
+    checked here without allocating such a tree (a valid tree.npz can reach it:
+    n3tree_query.hpp:22-47 descends anything)."""
+    L = _abi.lib()
+    look, desc = _abi.QUERY_LOOKUP, _abi.QUERY_DESCENT
+    assert L.vr_query_mode_for(2, 8, 2_000_000) == look          # lego-class
+    assert L.vr_query_mode_for(2, 23, 100) == look               # deepest leaf reads 24 child words
+    assert L.vr_query_mode_for(2, 24, 100) == desc
+    assert L.vr_query_mode_for(2, 29, 59) == desc
+    assert L.vr_query_mode_for(2, 9, (1 << 27) - 1) == look
+    assert L.vr_query_mode_for(2, 9, 1 << 27) == desc            # node * 8 + slot words * 4 bytes >= 2^32
+    assert L.vr_query_mode_for(2, 9, 1 << 40) == desc
+    assert L.vr_query_mode_for(3, 3, 100) == desc and L.vr_query_mode_for(4, 2, 10) == desc

@@ -106,3 +106,26 @@ def test_bench_two_gpus_over_rccl(gpu, mode):
     if mode == "tile":
         assert d["config"]["sharded_frame_matches_single_gpu"] is True
         assert d["parity"]["rgba8_equal"] is True  # the GATHERED frames of the timed region vs the oracle
+
+
+def test_bench_plain_form_launches_itself(gpu):
+    """`python bench.py --gpus 2` WITHOUT a launcher (how a driver may well call it): bench.py
+    re-executes itself under torch.distributed.run and relays rank 0's one line.  Shared-GPU
+    rehearsal on a one-GPU box; real RCCL between two devices where two are visible."""
+    import torch
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    two = torch.cuda.device_count() >= 2
+    if not two:
+        env["VOLREND_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C0",
+                        "--steps", "16", "--warmup", "8", "--batch", "4", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 16
+    assert d["config"]["sharded_frame_matches_single_gpu"] is True
+    assert ("REHEARSAL" in d["data"]) == (not two)
+    assert d["rccl"]["world_size"] == 2

@@ -384,3 +384,94 @@ def test_ray_order_is_scheduling_only(torch_cuda, frame_group, super_block):
         assert np.array_equal(imgs[i].cpu().numpy(), want[i]), ("frame", i)
         assert np.array_equal(outs[i].cpu().numpy(), want[i]), ("sharded", i)
     t.free_device()
+
+
+@pytest.mark.parametrize("fp_mode", [0, 1])
+@pytest.mark.parametrize("depth,step", [(26, 1e-8), (28, 1e-4), (30, 1e-8)])
+def test_n2_tree_beyond_the_integer_lookup_takes_the_float_descent(torch_cuda, depth, step, fp_mode):
+    """An N = 2 tree deeper than 24 levels cannot use the integer lookup (exact digits of a
+    binary32 coordinate): vr_tree_upload must route it to the literal float descent, which the
+    reference runs for every tree (n3tree_query.hpp:22-47).  A chain tree of 26-30 levels with
+    the camera INSIDE its deepest leaf (tests/common.py deep_chain_tree_n2): every ray starts at
+    depth `depth` and samples every level on its way out.  Kernel == oracle (both FP models,
+    accumulators, RGBA8, access counters) == the reference's own render_kernel / trace_ray
+    compiled for the host."""
+    import torch
+    from volrend_amd import _abi, api
+    tree, T = common.deep_chain_tree_n2(depth=depth, basis_dim=4, seed=depth)
+    tr, w, h, f = common.camera_at(T)
+    rgba_o, acc_o, cnt = common.oracle_frame(tree, tr, w, h, f, fp_mode, step_size=step)
+    assert cnt["hit_samples"] > 5000 and cnt["child_reads"] > 8 * cnt["samples"]
+    t = api.N3Tree.from_synth(tree)
+    info = t.info()
+    assert info["N"] == 2 and info["max_depth"] == depth - 1
+    assert info["query_mode"] == _abi.QUERY_DESCENT and info["top_levels"] == 0  # the fallback WAS taken
+    cam = api.Camera(w, h, f, f)
+    cam.transform = np.asarray(tr, np.float32)
+    img = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    counters = torch.zeros(7, dtype=torch.int64, device="cuda")
+    api.launch_renderer(t, cam, api.RenderOptions(step_size=step), img, None, None, True, accum=acc,
+                        counters=counters, fp_mode=fp_mode)
+    torch.cuda.synchronize()
+    assert t.status() == 0
+    cnt_g = dict(zip(_abi.COUNTER_FIELDS, [int(v) for v in counters.cpu().tolist()]))
+    # and once more without counters (the uninstrumented GENERIC flavour is the one a product launch takes)
+    img2 = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    api.launch_renderer(t, cam, api.RenderOptions(step_size=step), img2, None, None, True, fp_mode=fp_mode)
+    torch.cuda.synchronize()
+    t.free_device()
+    assert_parity(img.cpu().numpy(), acc.cpu().numpy(), rgba_o, acc_o)
+    assert np.array_equal(img2.cpu().numpy(), rgba_o)
+    assert cnt_g == cnt
+    if fp_mode == 0 and common.ob.ref_lib() is not None:
+        th = common.ob.TreeHandle(tree)
+        ocam = common.ob.make_camera(tr, w, h, f)
+        opt = common.ob.default_options(step_size=step)
+        assert np.array_equal(img.cpu().numpy(), common.ob.ref_render(th, ocam, opt)), "kernel != reference"
+        assert np.array_equal(acc.cpu().numpy().view(np.uint32),
+                              common.ob.ref_trace(th, ocam, opt).view(np.uint32)), "kernel != reference (fp32)"
+
+
+@pytest.mark.parametrize("raygen_waves", [16, 4, 1])
+@pytest.mark.parametrize("xcd_queues", [1, 0])
+def test_raygen_workgroup_size_is_scheduling_only(torch_cuda, raygen_waves, xcd_queues):
+    """Ray generation runs in workgroups of 16, 4 or 1 waves (small launches: one) and compacts the
+    rays of each of the 8 (or 1) ray queues to the front of the queue's own region, whose
+    boundaries lie at multiples of 16 blocks.  A 5-pose batch of a ragged image (block counts
+    that are no multiple of 16, queues of unequal length, rays that miss the volume) -- whole
+    frames and 3-way tile shards -- must equal the oracle whatever the workgroup size."""
+    torch = torch_cuda
+    from volrend_amd import api, synth
+    tree = common.small_scene(depth=5, basis_dim=9, seed=1311)
+    w, h = 150, 91
+    f = 1.9 * w   # narrow view from far away: many rays miss the volume
+    trs = [synth.c2w_to_transform(p) for p in synth.make_poses(5, radius=5.5)]
+    want = [common.oracle_frame(tree, tr, w, h, f)[0] for tr in trs]
+    t = api.N3Tree.from_synth(tree)
+    t.set_tuning(raygen_waves=raygen_waves, xcd_queues=xcd_queues)
+    cam = api.Camera(w, h, f, f)
+    imgs = torch.zeros((5, h, w, 4), dtype=torch.uint8, device="cuda")
+    api.launch_renderer_batch(t, cam, trs, api.RenderOptions(), [imgs[i] for i in range(5)], None, True)
+    torch.cuda.synchronize()
+    assert t.status() == 0
+    got = imgs.cpu().numpy()
+    for i in range(5):
+        assert np.array_equal(got[i], want[i]), f"pose {i}"
+    # tile shards: every rank's COMPACT buffer, assembled, equals the frame
+    from volrend_amd import tiles
+    for world in (3,):
+        parts = []
+        for rank in range(world):
+            shard = api.TileShard(16, 8, rank, world, compact=True)
+            nb = api.compact_bytes(w, h, shard)
+            buf = torch.zeros((5, nb), dtype=torch.uint8, device="cuda")
+            api.launch_renderer_batch(t, cam, trs, api.RenderOptions(), [buf[i] for i in range(5)], None, True,
+                                      shard=shard)
+            torch.cuda.synchronize()
+            parts.append(buf.cpu().numpy())
+        for i in range(5):
+            g = np.stack([parts[r][i].reshape(-1, 4) for r in range(world)])  # [world, compact pixels, 4]
+            frame = tiles.assemble_tiles(g, w, h, 16, 8, world)
+            assert np.array_equal(frame, want[i]), f"shard world {world} pose {i}"
+    t.free_device()

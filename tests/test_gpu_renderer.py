@@ -37,9 +37,15 @@ def exe(tmp_path_factory):
 CAMS = [(-3.0, 0.4, 2.2, -0.75, 0.1, 0.55), (2.5, -2.5, 1.0, 0.66, -0.66, 0.26), (0.3, 3.6, 0.8, 0.05, 0.97, 0.2)]
 
 
-@pytest.mark.parametrize("underlay", [False, True], ids=["cleared_frame", "mesh_underlay"])
+@pytest.mark.parametrize("underlay", [False, True, "stream"],
+                         ids=["cleared_frame", "mesh_underlay", "mesh_underlay_produced_on_a_stream"])
 @pytest.mark.parametrize("brightness", [1.0, 0.3])
 def test_volume_renderer_matches_oracle_compositing(exe, tmp_path, underlay, brightness):
+    """underlay == "stream": the underlay images are produced on a stream of the caller's right
+    before every render() and overwritten with junk right after it, with no host synchronisation
+    in between -- set_underlay(..., producer_stream) must order render()'s copies behind the
+    producer's work AND the producer's next writes behind the copies (the two frames alternate
+    between two streams, so "the stream of the last render()" orders nothing)."""
     basis_dim = 9
     tree = common.small_scene(depth=6, basis_dim=basis_dim, seed=501)
     w, h = 136, 96
@@ -59,6 +65,8 @@ def test_volume_renderer_matches_oracle_compositing(exe, tmp_path, underlay, bri
         rgba0.tofile(str(tmp_path / "u_rgba.raw"))
         depth0.tofile(str(tmp_path / "u_depth.raw"))
         spec.append(f"underlay {tmp_path / 'u_rgba.raw'} {tmp_path / 'u_depth.raw'}")
+        if underlay == "stream":
+            spec.append("underlay_stream 1")
     else:  # glClear: (b, b, b, 1) as RGBA8, depth 1e9 (cuda_renderer.cpp:85-92)
         c = int(np.floor(min(max(brightness, 0.0), 1.0) * 255.0 + 0.5))
         rgba0 = np.empty((h, w, 4), dtype=np.uint8)

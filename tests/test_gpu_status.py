@@ -48,6 +48,11 @@ def test_status_word_through_the_api(torch_cuda):
     assert t.status() & 1, "rays were cut by the guard but the status word says nothing"
     assert not np.array_equal(img.cpu().numpy(), want), "cut rays cannot give the right picture"
     assert t.status(reset=True) & 1 and t.status() == 0  # sticky until reset
+    # the same word read ON the launch's stream (vr_tree_status_on: that stream alone is waited for)
+    side = torch.cuda.Stream()
+    api.launch_renderer(t, cam, api.RenderOptions(), img, None, side, True)
+    assert t.status(stream=side) & 1, "the read on the launch's own stream must see its bit"
+    assert t.status(reset=True, stream=side) & 1 and t.status(stream=side) == 0 and t.status() == 0
     t.set_tuning(max_iter=1 << 22)
     api.launch_renderer(t, cam, api.RenderOptions(), img, None, None, True)
     torch.cuda.synchronize()

@@ -217,3 +217,43 @@ def test_drain_simulation_conserves_rays():
     assert clocks > 0 and 0 < len(left) < len(rays) and left.min() >= 1
     total, n_phases = ds.simulate(rays, "phased", T=16, n_waves=128)
     assert n_phases >= 2 and total > clocks
+
+
+def test_bench_self_launch_command_and_relay(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself under
+    torch.distributed.run (the driver's documented form): argv, port, environment -- and the
+    relay of rank 0's one JSON line + the exit code (the launcher itself is faked here)."""
+    import json as _json
+    import subprocess
+    import sys as _sys
+    import bench
+    cmd = bench.self_launch_command(["--gpus", "4", "--steps", "20", "--warmup", "5"], 4, port=29999)
+    assert cmd[:3] == [_sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29999"
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    # a free port is picked when none is given
+    p = int(bench.self_launch_command([], 2)[bench.self_launch_command([], 2).index("--master-port") + 1])
+    assert 1024 < p < 65536
+
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 3
+            stdout = b'NCCL version banner\n{"metric": "x", "n_gpus": 2}\n'
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setenv("RANK", "7")  # stale launcher variables must not reach the new launcher
+    out = tmp_path / "out.txt"
+    with open(out, "w") as f:
+        monkeypatch.setattr(_sys, "stdout", f)
+        rc = bench.self_launch(["--gpus", "2"], 2)
+    assert rc == 3
+    assert "RANK" not in seen["env"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert _json.loads(out.read_text().strip()) == {"metric": "x", "n_gpus": 2}

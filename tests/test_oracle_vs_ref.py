@@ -180,3 +180,20 @@ def test_random_configurations_bit_exact(seed):
     assert np.array_equal(rgba_o, rgba_r), (fmt, bd, kw)
     acc_r = ob.ref_trace(th, cam, opt)
     assert np.array_equal(acc_o.view(np.uint32), acc_r.view(np.uint32)), (fmt, bd, kw)
+
+
+@pytest.mark.parametrize("depth,step", [(26, 1e-8), (28, 1e-4), (30, 1e-8)])
+def test_deep_n2_chain_tree(depth, step):
+    """Trees deeper than 24 levels (the kernels' float-descent fallback for N = 2,
+    tests/test_gpu_parity.py): the oracle's root descent equals the reference's
+    query_single_from_root (n3tree_query.hpp:22-47) at every depth the format allows -- the camera
+    sits inside the deepest leaf of a 26-30 level chain and every ray samples every level."""
+    tree, T = common.deep_chain_tree_n2(depth=depth, basis_dim=4, seed=depth)
+    tr, w, h, f = common.camera_at(T)
+    th = ob.TreeHandle(tree)
+    cam = ob.make_camera(tr, w, h, f)
+    opt = ob.default_options(step_size=step)
+    rgba_o, acc_o, cnt = ob.render(th, cam, opt, ob.FP_STRICT)
+    assert cnt["hit_samples"] > 5000 and cnt["child_reads"] > 8 * cnt["samples"]
+    assert np.array_equal(rgba_o, ob.ref_render(th, cam, opt))
+    assert np.array_equal(acc_o.view(np.uint32), ob.ref_trace(th, cam, opt).view(np.uint32))

@@ -76,7 +76,7 @@ def main():
         for st in (1, 2):
             out[f"batch{b}_streams{st}"] = run(common + ["--batch", str(b), "--streams", str(st)])
     # the reference's own launch shape -- one pose per launch -- and small launches, on one stream and
-    # on two alternating ones (--streams 0 = auto picks 2 below 8 poses per launch)
+    # on two alternating ones (--streams 0 = auto picks 2 below 48 poses per launch)
     for b in (1, 4):
         for st in (1, 2):
             out[f"batch{b}_streams{st}"] = run(common + ["--batch", str(b), "--streams", str(st)])

@@ -18,6 +18,7 @@ VR_OK = 0
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 FORMATS = {"RGBA": FORMAT_RGBA, "SH": FORMAT_SH, "SG": FORMAT_SG, "ASG": FORMAT_ASG}
 FP_STRICT, FP_FMA = 0, 1
+QUERY_LOOKUP, QUERY_DESCENT = 0, 1  # VrTreeInfo.query_mode
 LAYOUT_FRAME, LAYOUT_COMPACT = 0, 1
 MAX_BASIS = 25
 
@@ -38,7 +39,9 @@ class VrQuantDesc(C.Structure):
 class VrTreeInfo(C.Structure):
     _fields_ = [("capacity", C.c_int64), ("N", C.c_int32), ("data_dim", C.c_int32),
                 ("format", C.c_int32), ("basis_dim", C.c_int32), ("max_depth", C.c_int32),
-                ("device", C.c_int32), ("device_bytes", C.c_uint64), ("leaf_stride", C.c_uint64)]
+                ("device", C.c_int32), ("device_bytes", C.c_uint64), ("leaf_stride", C.c_uint64),
+                ("query_mode", C.c_int32), ("top_levels", C.c_int32), ("brick_levels", C.c_int32),
+                ("brick_blocked", C.c_int32)]
 
 
 class VrCamera(C.Structure):
@@ -85,6 +88,7 @@ PROTOTYPES = {
     "vr_tree_clone": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "vr_tree_free": (C.c_int, [C.c_void_p]),
     "vr_tree_info": (C.c_int, [C.c_void_p, C.POINTER(VrTreeInfo)]),
+    "vr_query_mode_for": (C.c_int, [C.c_int, C.c_int, C.c_int64]),
     "vr_default_options": (None, [C.POINTER(VrRenderOptions)]),
     "vr_default_frame": (None, [C.POINTER(VrFrame)]),
     "vr_compact_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -96,6 +100,7 @@ PROTOTYPES = {
     "vr_reserve_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int]),
     "vr_tree_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
+    "vr_tree_status_on": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_void_p]),
     "vr_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "vr_tree_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "vr_sched_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 8), C.c_int]),

@@ -359,10 +359,16 @@ class N3Tree:
         for k, v in kw.items():
             _abi.check(_abi.lib().vr_tree_set_tuning(self.handle, k.encode(), int(v)))
 
-    def status(self, reset: bool = False) -> int:
-        """Sticky device status word (vr_tree_status): bit 0 = a ray hit the sample guard."""
+    def status(self, reset: bool = False, stream=None) -> int:
+        """Sticky device status word (vr_tree_status): bit 0 = a ray hit the sample guard.
+        With ``stream``: read ON that stream and wait for it alone (vr_tree_status_on) -- other
+        streams that render this tree are not waited for."""
         out = C.c_uint32(0)
-        _abi.check(_abi.lib().vr_tree_status(self.handle, C.byref(out), 1 if reset else 0))
+        if stream is not None:
+            _abi.check(_abi.lib().vr_tree_status_on(self.handle, C.byref(out), 1 if reset else 0,
+                                                    _stream_ptr(stream)))
+        else:
+            _abi.check(_abi.lib().vr_tree_status(self.handle, C.byref(out), 1 if reset else 0))
         return int(out.value)
 
     def info(self) -> dict:

@@ -78,15 +78,28 @@ void launch_renderer_batch(const N3Tree& tree, const Camera& cam,
     }
 }
 
-void check_render_status(const N3Tree& tree) {
-    if (!tree.device) return;
-    uint32_t status = 0;
-    check(vr_tree_status(tree.device, &status, 1), "vr_tree_status");
+namespace {
+void throw_on_status(uint32_t status) {
     if (status != 0)
         throw std::runtime_error(
             "render status 0x" + std::to_string(status) +
             ": rays hit the sample guard (step_size too small for this scene?): the frames of "
             "these launches are wrong");
+}
+}  // namespace
+
+void check_render_status(const N3Tree& tree) {
+    if (!tree.device) return;
+    uint32_t status = 0;
+    check(vr_tree_status(tree.device, &status, 1), "vr_tree_status");
+    throw_on_status(status);
+}
+
+void check_render_status(const N3Tree& tree, void* stream) {
+    if (!tree.device) return;
+    uint32_t status = 0;
+    check(vr_tree_status_on(tree.device, &status, 1, stream), "vr_tree_status_on");
+    throw_on_status(status);
 }
 
 }  // namespace volrend

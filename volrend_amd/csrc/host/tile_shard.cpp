@@ -266,16 +266,20 @@ void TileShardRenderer::sync() {
         hip_ok(hipStreamSynchronize(hs(comm_stream_[r])), "hipStreamSynchronize");
     }
     hip_ok(hipSetDevice(prev), "hipSetDevice");
-    // every launch has run: a rank whose rays hit the sample guard rendered wrong tiles
+    // every launch has run: a rank whose rays hit the sample guard rendered wrong tiles.  ALL ranks'
+    // words are read and cleared before anything is thrown -- a later sync() must not trip over
+    // stale bits of these launches
+    std::string failed;
     for (int r = 0; r < n_; ++r) {
         uint32_t status = 0;
         vr_ok(vr_tree_status(tree_[r], &status, 1), "vr_tree_status");
         if (status != 0)
-            throw std::runtime_error("tile shard: rank " + std::to_string(r) + " reports render status 0x" +
-                                     std::to_string(status) +
-                                     " (rays hit the sample guard: step_size too small for this scene?); "
-                                     "the frames are wrong");
+            failed += (failed.empty() ? "" : ", ") + std::to_string(r) + " (0x" + std::to_string(status) + ")";
     }
+    if (!failed.empty())
+        throw std::runtime_error("tile shard: render status of rank(s) " + failed +
+                                 " (rays hit the sample guard: step_size too small for this scene?); "
+                                 "the frames are wrong");
 }
 
 }  // namespace internal

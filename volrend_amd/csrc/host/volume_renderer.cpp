@@ -53,6 +53,9 @@ struct VolumeRenderer::Impl {
     const void* under_rgba = nullptr;
     const float* under_depth = nullptr;
     int under_w = 0, under_h = 0;  // the size the underlay buffers were handed in for
+    hipStream_t under_stream = nullptr;  // where the underlay is produced (nullptr: ordered by the host)
+    bool under_ordered = false;          // (set_underlay was given a producer stream)
+    hipEvent_t under_ready = nullptr, under_taken = nullptr;
     int device = -1;               // where stream and frames live (-1: nothing created yet)
 
     // The tree's device (the current one while no tree is set).  Moving to another device drops
@@ -115,6 +118,8 @@ struct VolumeRenderer::Impl {
         release();
         for (auto st : streams)
             if (st) (void)hipStreamDestroy(st);
+        if (under_ready) (void)hipEventDestroy(under_ready);
+        if (under_taken) (void)hipEventDestroy(under_taken);
     }
 };
 
@@ -136,6 +141,15 @@ void VolumeRenderer::render() {
     uint8_t* frame = m.rgba[m.buf_index];
     float* depth = m.depth[m.buf_index];
     hipStream_t stream = m.streams[m.buf_index];  // the frame's own stream (see Impl)
+    const bool ordered = m.under_ordered && (m.under_rgba || m.under_depth);
+    if (ordered) {  // the copies below wait for what the producer has enqueued so far
+        if (!m.under_ready) {
+            hip_check(hipEventCreateWithFlags(&m.under_ready, hipEventDisableTiming), "hipEventCreate");
+            hip_check(hipEventCreateWithFlags(&m.under_taken, hipEventDisableTiming), "hipEventCreate");
+        }
+        hip_check(hipEventRecord(m.under_ready, m.under_stream), "hipEventRecord(underlay ready)");
+        hip_check(hipStreamWaitEvent(stream, m.under_ready, 0), "hipStreamWaitEvent(underlay ready)");
+    }
     // glClearNamedFramebufferfv: colour = (b, b, b, 1) converted to RGBA8 the GL way
     // (round(clamp(b, 0, 1) * 255)), depth attachment = 1e9 (cuda_renderer.cpp:85-92)
     if (m.under_rgba) {
@@ -157,6 +171,10 @@ void VolumeRenderer::render() {
         __builtin_memcpy(&bits, &inf, 4);
         hip_check(hipMemsetD32Async((hipDeviceptr_t)depth, (int)bits, px, stream),
                   "hipMemsetD32Async(depth)");
+    }
+    if (ordered) {  // ... and the producer's next writes wait for the copies
+        hip_check(hipEventRecord(m.under_taken, stream), "hipEventRecord(underlay taken)");
+        hip_check(hipStreamWaitEvent(m.under_stream, m.under_taken, 0), "hipStreamWaitEvent(underlay taken)");
     }
     camera._update();  // cuda_renderer.cpp:97
     if (m.tree != nullptr)  // cuda_renderer.cpp:114-120: the interactive path composites (offscreen = false)
@@ -189,9 +207,11 @@ void VolumeRenderer::resize(int width, int height) {  // cuda_renderer.cpp:128-1
 
 const char* VolumeRenderer::get_backend() { return "HIP"; }  // upstream: "CUDA" (cuda_renderer.cpp:225)
 
-void VolumeRenderer::set_underlay(const void* rgba8_dev, const float* depth_dev) {
+void VolumeRenderer::set_underlay(const void* rgba8_dev, const float* depth_dev, void* producer_stream) {
     impl_->under_rgba = rgba8_dev;
     impl_->under_depth = depth_dev;
+    impl_->under_stream = static_cast<hipStream_t>(producer_stream);
+    impl_->under_ordered = producer_stream != nullptr;
     impl_->under_w = camera.width;
     impl_->under_h = camera.height;
 }
@@ -206,10 +226,18 @@ void VolumeRenderer::read_frame(void* host_rgba8) {
     OnDevice on(m.device);
     hip_check(hipMemcpyAsync(host_rgba8, m.rgba[m.last], (size_t)m.width * m.height * 4,
                              hipMemcpyDeviceToHost, m.streams[m.last]), "hipMemcpyAsync(read_frame)");
-    hip_check(hipStreamSynchronize(m.streams[m.last]), "hipStreamSynchronize");
-    // the stream is idle: what the launches found out on the device (the sample guard) surfaces
-    // here, loudly, instead of a wrong frame handed out as a good one
-    if (m.tree) check_render_status(*m.tree);
+    // what the launches found out on the device (the sample guard) surfaces here, loudly, instead of
+    // a wrong frame handed out as a good one -- read on THIS frame's stream, behind its copy: the
+    // other frame's launch, if one is in flight, is not waited for
+    if (m.tree)
+        check_render_status(*m.tree, m.streams[m.last]);
+    else
+        hip_check(hipStreamSynchronize(m.streams[m.last]), "hipStreamSynchronize");
+}
+
+void* VolumeRenderer::next_stream() {
+    impl_->start();
+    return impl_->streams[impl_->buf_index];
 }
 
 void* VolumeRenderer::stream() const {  // the stream of the frame frame() names

@@ -46,6 +46,7 @@ struct Tuning {
     int records_nt = -1;   // record stream non-temporal: -1 = by lookup-structure size, 0 / 1 = forced
     int xcd_queues = 1;
     int chunk_max = 4096;
+    int raygen_waves = 0;  // waves per ray-generation workgroup: 16 / 4 / 1; 0 = by launch size (vr_render_batch)
     int top_levels = 0;    // lookup structure built at upload (vr_kernels.hip); 0 = auto
     int brick_levels = 3;
     int brick_blocked = -1;  // 8^3 bricks in 4 x 4 x 2 line blocks: -1 = when the lookup structure exceeds 128 MB, 0 / 1 = forced
@@ -65,6 +66,7 @@ Tuning& default_tuning_locked() {  // call with g_tuning_mutex held
         if (const char* e = getenv("VR_RECORDS_NT")) x.records_nt = atoi(e);
         if (const char* e = getenv("VR_XCD_QUEUES")) x.xcd_queues = atoi(e) != 0;
         if (const char* e = getenv("VR_CHUNK_MAX")) x.chunk_max = atoi(e) < 64 ? 64 : (atoi(e) & ~63);
+        if (const char* e = getenv("VR_RAYGEN_WAVES")) x.raygen_waves = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("VR_TOP_LEVELS")) x.top_levels = atoi(e);
         if (const char* e = getenv("VR_BRICK_LEVELS")) x.brick_levels = atoi(e);
         if (const char* e = getenv("VR_BRICK_BLOCKED")) x.brick_blocked = atoi(e);
@@ -87,6 +89,7 @@ bool set_tuning_key(Tuning& tn, const char* key, int value) {
     else if (!strcmp(key, "records_nt")) tn.records_nt = value < 0 ? -1 : (value != 0);
     else if (!strcmp(key, "xcd_queues")) tn.xcd_queues = value != 0;
     else if (!strcmp(key, "chunk_max")) tn.chunk_max = value < 64 ? 64 : (value & ~63);
+    else if (!strcmp(key, "raygen_waves")) tn.raygen_waves = value < 0 ? 0 : value;
     else if (!strcmp(key, "top_levels")) tn.top_levels = value;
     else if (!strcmp(key, "brick_levels")) tn.brick_levels = value;
     else if (!strcmp(key, "brick_blocked")) tn.brick_blocked = value < 0 ? -1 : (value != 0);
@@ -128,7 +131,7 @@ class DeviceGuard {
 }  // namespace
 
 constexpr unsigned kLaunchSlots = 8;
-constexpr unsigned kSlotWords = 160;  // [0] ray count, [16 + 16*x] queue head x (x < 8)
+constexpr unsigned kSlotWords = 160;  // [16 + 16*x] queue x (x < 8): rays handed out, rays stored
 
 // Per-launch scratch that a kernel reads while it runs: frame table, queue heads, ray count,
 // ray buffer, probe coefficients.  `done` is recorded on the launch's stream behind its last
@@ -543,7 +546,9 @@ bool ray_carries_vdir(const VrTreeOpaque* t) {
 int ray_tail_words_of(const VrTreeOpaque* t) { return ray_carries_vdir(t) ? 3 : basis_words_of(t); }
 
 size_t ray_buffer_bytes(uint32_t total_rays, int tail_words) {
-    return (size_t)total_rays * (16 + (size_t)tail_words) * sizeof(uint32_t);  // kRayWords + tail
+    // the ray queues own whole groups of 16 blocks of 64 rays (vr_kernels.hip "Ray queues")
+    const size_t slots = (((size_t)total_rays / 64 + 15) / 16) * 16 * 64;
+    return slots * (16 + (size_t)tail_words) * sizeof(uint32_t);  // kRayWords + tail
 }
 
 void fill_tree_params(vr::KParams& k, const VrTreeOpaque* t) {
@@ -846,7 +851,7 @@ static int upload_body(const VrTreeDesc* d, const VrQuantDesc* q, vr_tree_t* out
     // digits of a binary32 coordinate) and node*8+slot byte offsets must fit 32 bits.
     int G0 = 0, BL = 0;
     const Tuning tn = default_tuning();  // the new tree's own copy from here on
-    if (d->N == 2 && max_depth <= 23 && d->capacity < (1ll << 27)) {
+    if (vr_query_mode_for(d->N, max_depth, d->capacity) == VR_QUERY_LOOKUP) {
         // auto: top grid + brick reach the deepest leaf (depth max_depth + 1) without a child-word
         // walk where a top grid of <= 256^3 cells allows it -- 64^3 (2 MB) for lego-class trees of
         // 9 levels, 128^3 for 10 (measured: C1 0.269 ms at (6,3) against 0.301 at (5,3); C3 0.790
@@ -1110,7 +1115,17 @@ int vr_tree_info(vr_tree_t t, VrTreeInfo* info) {
     info->device = t->device;
     info->device_bytes = t->device_bytes;
     info->leaf_stride = (uint64_t)t->leaf_stride_h * 2u;
+    info->query_mode = t->top_levels > 0 ? VR_QUERY_LOOKUP : VR_QUERY_DESCENT;
+    info->top_levels = t->top_levels;
+    info->brick_levels = t->brick_levels;
+    info->brick_blocked = t->brick_blocked;
     return VR_OK;
+}
+
+// The integer lookup needs exact digits of a binary32 coordinate (leaves within 24 levels: child
+// words read <= 24) and 32-bit byte offsets into the node array (node * 8 + slot words < 2^30).
+int vr_query_mode_for(int N, int max_depth, int64_t capacity) {
+    return (N == 2 && max_depth <= 23 && capacity < (1ll << 27)) ? VR_QUERY_LOOKUP : VR_QUERY_DESCENT;
 }
 
 void vr_default_options(VrRenderOptions* o) {
@@ -1402,10 +1417,8 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
     LaunchSlot& ls = t->slots[slot];
     k.frames = t->slot_frames + (size_t)slot * vr::kMaxBatch;
     k.queue_head = t->slot_heads + kSlotWords * slot + 16;
-    k.ray_count_rw = t->slot_heads + kSlotWords * slot;
     k.n_queues = tn.xcd_queues ? 8 : 1;
     k.chunk_max = tn.chunk_max;
-    k.ray_count = k.ray_count_rw;
     k.basis_words = basis_words_of(t);
     k.ray_tail_words = ray_tail_words_of(t);
     k.ray_vdir = ray_carries_vdir(t) ? 1 : 0;
@@ -1480,7 +1493,13 @@ int vr_render_batch(vr_tree_t t, int n_frames, const VrCamera* cams, const VrRen
         }
         HIP_TRY(vr::launch_prepare(k, tbl, hs));
     }
-    HIP_TRY(vr::launch_render(k, f->fp_mode, t->n_cus, tn.waves_per_cu, hs));
+    // waves per ray-generation workgroup: 16 (one atomic per 1024 pixels) -- except launches of one or
+    // two frames, the ones that run beside the tail of a neighbour on another stream: workgroups of
+    // 4 waves find room there much earlier (vr_kernels.hip raygen_kernel; profiles/r06_raygen_waves.jsonl:
+    // two streams -10 % / -6.5 % at one / two frames per launch, one stream +-0; from four frames on the
+    // 4x atomics cost a lone launch 3-4 %, and one-wave workgroups 35 %)
+    const int gen_waves = tn.raygen_waves > 0 ? tn.raygen_waves : (n_frames <= 2 ? 4 : 16);
+    HIP_TRY(vr::launch_render(k, f->fp_mode, t->n_cus, tn.waves_per_cu, gen_waves, hs));
     return VR_OK;  // (`seal` records the slot's event)
 }
 
@@ -1533,6 +1552,20 @@ int vr_tree_status(vr_tree_t t, uint32_t* status, int reset) {
     DeviceGuard guard(t->device);
     HIP_TRY(hipMemcpy(status, t->status, sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(hipMemset(t->status, 0, sizeof(uint32_t)));
+    return VR_OK;
+}
+
+int vr_tree_status_on(vr_tree_t t, uint32_t* status, int reset, void* stream) {
+    if (!t || !status) return fail(VR_ERR_INVALID_ARGUMENT, "NULL argument");
+    DeviceGuard guard(t->device);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    // a pinned word per calling thread: the copy is asynchronous and ordered on `hs` alone
+    thread_local uint32_t* pinned = nullptr;
+    if (!pinned) HIP_TRY(hipHostMalloc((void**)&pinned, sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(pinned, t->status, sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
+    if (reset) HIP_TRY(hipMemsetAsync(t->status, 0, sizeof(uint32_t), hs));
+    HIP_TRY(hipStreamSynchronize(hs));
+    *status = *pinned;
     return VR_OK;
 }
 

@@ -89,13 +89,11 @@ struct KParams {
     int64_t n_wave_blocks;       // per frame: n_local_tiles * wblocks_per_tile
     uint32_t total_rays;         // n_frames * n_wave_blocks * 64
     // ---- persistent scheduling ----
-    uint32_t* queue_head;        // 8 head words, 16 words apart, reset by prepare_launch_kernel
+    uint32_t* queue_head;        // 8 x (head, count) word pairs, 16 words apart, reset by prepare_launch_kernel
     int32_t n_queues;            // 1 or 8 (one ray-id range per XCD)
     int32_t chunk_max;           // largest ray-id chunk a wave takes at once (multiple of 64)
-    const uint32_t* ray_buf;     // compacted rays (written by raygen_kernel), SoA, stride total_rays
-    uint32_t* ray_buf_rw;
-    const uint32_t* ray_count;   // number of rays in ray_buf
-    uint32_t* ray_count_rw;
+    const uint32_t* ray_buf;     // rays (written by raygen_kernel), blocked SoA; queue x's rays compacted to the
+    uint32_t* ray_buf_rw;        // front of its region (vr_kernels.hip "Ray queues")
     int32_t basis_words;         // basis_fn values a ray carries in registers (0 for RGBA)
     int32_t ray_tail_words;      // words of a ray record behind its 16-word head: the 3 words of the
                                  // view direction (ray_vdir) or the basis_words basis values
@@ -120,7 +118,7 @@ struct KParams {
 
 // vr_kernels.hip
 hipError_t launch_prepare(const KParams& p, const FrameTable& tbl, hipStream_t stream);
-hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_override,
+hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_override, int gen_waves,
                          hipStream_t stream);
 hipError_t launch_assemble(uint8_t* frame, int64_t pitch, const uint8_t* gathered, int width,
                            int height, int tile_w, int tile_h, int world, int n_frames,

@@ -48,7 +48,8 @@ constexpr int kWave = 64;
 #define VR_PACKED_EXP 1       // the sigmoids of channels 0/1 share packed mul / fma / add instructions
 #endif
 // Guard against rays that never end (upstream would spin forever): KParams.max_iter march rounds
-// of a wave without a single retired ray, default 2^22 (tuning key `max_iter`, for tests).
+// of a wave since its last retire / refill pass that retired a ray, default 2^22 (tuning key
+// `max_iter`, for tests).
 
 enum { BASIS_RGBA = -1, BASIS_1 = 1, BASIS_4 = 4, BASIS_9 = 9, BASIS_16 = 16, BASIS_25 = 25 };
 
@@ -824,17 +825,26 @@ __device__ __forceinline__ T* ray_slot(T* buf, int words_per_ray, uint32_t r) {
 }
 __device__ __forceinline__ uint32_t ray_word(const uint32_t* slot, int k) { return slot[k * 64]; }
 constexpr int kRing = 128;   // capacity; at most 127 items are ever outstanding
-constexpr int kQueueStride = 16;  // words between queue heads (one 64-byte line each)
+constexpr int kQueueStride = 16;  // words between queue heads (one 64-byte line each: head, count)
 #ifndef VR_STEAL_MIN
 #define VR_STEAL_MIN 8192  // rays a foreign queue must still hold to be worth a steal (or an eighth of its length)
 #endif
 
-// A wave's next private range [lo, hi) of ray ids, or lo == hi when there is nothing left for it.
-// The ray buffer is cut into n_queues (1 or 8) contiguous ranges (= screen regions of the batch,
-// see locate()), each with its own head word; a wave serves the range of its XCD first
-// (workgroup b runs on XCD b % 8 -- used for L2 affinity only, never for correctness) and steals
-// from the others when that range has run dry.  Chunk sizes shrink as a queue drains (guided
-// self-scheduling) so the tail stays balanced.
+// Ray queues.  The 8x8 pixel blocks of a launch (ray-id order: locate()) are cut into n_queues (1 or
+// 8) contiguous runs -- screen regions of the batch -- at multiples of 16 blocks; queue x owns the ray
+// slots of its blocks, [first_block(x) * 64, first_block(x + 1) * 64), and two words of one 64-byte
+// line: head (rays handed out, render_kernel) and count (rays stored, raygen_kernel).  Ray generation
+// compacts the rays that enter the volume to the front of their queue's region (one atomic on the
+// queue's count word per workgroup: eight words share the load a single counter carried, which is
+// what lets small launches generate their rays in workgroups of one or four waves, below).
+__device__ __forceinline__ uint32_t queue_first_block(uint32_t n_groups16, uint32_t x, uint32_t sh) {
+    return (uint32_t)(((uint64_t)n_groups16 * x) >> sh) << 4;
+}
+
+// A wave's next private range [lo, hi) of ray slots, or lo == hi when there is nothing left for it.
+// A wave serves the queue of its XCD first (workgroup b runs on XCD b % 8 -- used for L2 affinity
+// only, never for correctness) and steals from the others when that queue has run dry.  Chunk sizes
+// shrink as a queue drains (guided self-scheduling) so the tail stays balanced.
 //   * One lane walks the queues: one load per queue, and ONE returning atomic on the queue that is
 //     picked.  A single word sustains ~90 accesses per microsecond chip-wide (one queue for the
 //     whole chip: a one-frame launch takes 40 % longer, profiles/r03_steal_threshold.jsonl).
@@ -847,20 +857,18 @@ constexpr int kQueueStride = 16;  // words between queue heads (one 64-byte line
 //     A wave only reports "nothing left" after its OWN queue has run dry, so every queue is
 //     drained by the waves it belongs to -- which a grid of fewer waves than queues does not
 //     have for every queue: such a grid steals to the end.
-__device__ __forceinline__ void grab_chunk(const KParams& p, uint32_t total, int lane, uint32_t& lo,
-                                           uint32_t& hi) {
+__device__ __forceinline__ void grab_chunk(const KParams& p, int lane, uint32_t& lo, uint32_t& hi) {
     lo = hi = 0;
     if (lane == 0) {
         const uint32_t nq = (uint32_t)p.n_queues;  // 1 or 8
-        const uint32_t sh = nq == 8u ? 3u : 0u;    // queue x = ray ids [total * x / nq, total * (x + 1) / nq)
+        const uint32_t sh = nq == 8u ? 3u : 0u;
+        const uint32_t n16 = ((p.total_rays >> 6) + 15u) >> 4;
         const uint32_t mine = blockIdx.x & (nq - 1u);
         const uint32_t waves_per_q = (gridDim.x + nq - 1u) >> sh;
-        for (uint32_t a = 0; a < (VR_EXP_STEAL ? nq : 1u); ++a) {
+        for (uint32_t a = 0; a < nq; ++a) {
             const uint32_t x = (mine + a) & (nq - 1u);
-            const uint32_t qlo = (uint32_t)((uint64_t)total * x >> sh);
-            const uint32_t qhi = (uint32_t)((uint64_t)total * (x + 1u) >> sh);
-            const uint32_t len = qhi - qlo;
             uint32_t* head = p.queue_head + x * kQueueStride;
+            const uint32_t len = head[1];  // rays of this queue (written by raygen_kernel, constant here)
             const uint32_t seen = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (seen >= len) continue;
             if (a != 0u && gridDim.x >= nq &&
@@ -871,8 +879,9 @@ __device__ __forceinline__ void grab_chunk(const KParams& p, uint32_t total, int
             size &= ~63u;
             const uint32_t base = atomicAdd(head, size);
             if (base < len) {
+                const uint32_t qlo = queue_first_block(n16, x, sh) << 6;
                 lo = qlo + base;
-                hi = base + size < len ? qlo + base + size : qhi;
+                hi = qlo + (base + size < len ? base + size : len);
                 break;
             }
         }
@@ -1000,7 +1009,6 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     bool exhausted = false;  // the ray buffer has been handed out completely
     uint32_t chunk_next = 0, chunk_end = 0;  // this wave's private range of ray ids
     uint32_t ring_head = 0, ring_tail = 0;  // items [head, tail) are waiting for a shader lane
-    const uint32_t total = *p.ray_count;  // rays that entered the volume (raygen_kernel)
     const int wpr = kRayWords + p.ray_tail_words;  // words per ray in the ray buffer
     // scheduling statistics (instrumented flavours only): rounds and busy lanes per phase
     uint32_t st_march_r = 0, st_march_l = 0, st_shade_r = 0, st_shade_l = 0, st_distinct = 0,
@@ -1174,8 +1182,11 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
             }
             const bool vacant = done || !ray.active;
             bool take = false;
-            // (a ray retired: the wave makes progress.  Both counters are wave-uniform; saying so keeps
-            // them in scalar registers -- as vector values they cost the SH16 flavour its last two)
+            // (a ray retires in this pass: the wave makes progress.  A finished ray that still WAITS for a
+            // pass -- fewer than refill_min idle lanes -- does not count: were it to, a wave that holds one
+            // finished and one endless ray after the queues ran dry would never trip the guard.  Both
+            // counters are wave-uniform; saying so keeps them in scalar registers -- as vector values they
+            // cost the SH16 flavour its last two)
             if (m_done != 0ull) progress_round = (uint32_t)__builtin_amdgcn_readfirstlane((int)rounds);
             // Idle lanes take consecutive rays from the buffer.  The wave owns a private
             // chunk [chunk_next, chunk_end) of ray ids and only goes to the global queue
@@ -1184,7 +1195,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
             // queue drains (guided self-scheduling) so the tail stays balanced.
             if (!exhausted && chunk_next >= chunk_end) {
                 uint32_t lo, hi;
-                grab_chunk(p, total, lane, lo, hi);
+                grab_chunk(p, lane, lo, hi);
                 lo = __builtin_amdgcn_readfirstlane(lo);
                 hi = __builtin_amdgcn_readfirstlane(hi);
                 if (hi == lo) {
@@ -1263,7 +1274,9 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         // ---- march: lanes with a live ray and room for another outstanding item ----
         TL_ADD(tl_refill);
         // Guard against rays that never end (not in the reference, which would spin): when the
-        // wave has marched p.max_iter rounds without retiring a single ray, whatever is still
+        // wave has marched p.max_iter rounds since its last retire / refill pass that retired a ray
+        // (progress_round above: with the default of 2^22 rounds the difference to "without a
+        // retired ray" is nil; a lowered max_iter trips earlier the larger refill_min is), whatever is still
         // marching is cut and reported (sticky status bit 0: the host layers fail loudly on it;
         // WHICH rays share a wave depends on the scheduling knobs, so the pixels of a launch that
         // tripped the guard are not tuning-independent -- they are wrong either way).  Wave-uniform
@@ -1412,16 +1425,24 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
 // ray buffer -- each wave compacts its survivors with a ballot / mbcnt prefix
 // count and reserves their slots with ONE atomic.
 // ---------------------------------------------------------------------------
-constexpr int kGenWaves = 16;  // waves (8x8 pixel blocks) per raygen workgroup
+// Waves (8x8 pixel blocks) per raygen workgroup: 16, 4 or 1 (launch_render picks; tuning key
+// raygen_waves).  16 for batches: one atomic per 1024 pixels.  Launches of one or two frames -- the
+// ones whose neighbour on another stream is still draining -- use 4: a workgroup of 16 waves needs
+// four free wave slots AND 256 free vector registers on every SIMD of one CU at the same moment,
+// which the previous launch's render kernel (5 waves x 96 registers per SIMD) does not offer until
+// it is nearly done: the ray generation of launch k + 1 took 135 us instead of 16 beside the tail
+// of launch k (kernel trace, profiles/r06_overlap_trace.jsonl), 51 with workgroups of 4 -- and the
+// render kernel of launch k + 1 cannot start before it has ended.  Smaller workgroups mean more
+// atomics: at 4 waves a 64-frame launch is 4 % slower, at 1 wave 35 % (profiles/r06_raygen_waves.jsonl).
 
-template <int FMA, bool FULL>
-__global__ __launch_bounds__(kWave* kGenWaves) void raygen_kernel(const KParams p) {
-    __shared__ uint32_t wave_count[kGenWaves];
-    __shared__ uint32_t wave_base[kGenWaves];
+template <int FMA, bool FULL, int GW>
+__global__ __launch_bounds__(kWave* GW) void raygen_kernel(const KParams p) {
+    __shared__ uint32_t wave_count[GW];
+    __shared__ uint32_t wave_base[GW];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const uint32_t id =
-        (uint32_t)(((int64_t)blockIdx.x * kGenWaves + wave) * kWave + lane);
+        (uint32_t)(((int64_t)blockIdx.x * GW + wave) * kWave + lane);
     bool valid = false;
     Ray nr;
     uint8_t* px = nullptr;
@@ -1443,28 +1464,46 @@ __global__ __launch_bounds__(kWave* kGenWaves) void raygen_kernel(const KParams 
             }
         }
     }
-    // Compaction: wave ballot + mbcnt prefix inside the wave, a 16-entry scan over the
-    // workgroup's waves, and ONE atomic per workgroup on the ray counter (a single
-    // word only sustains ~90 returning atomics per microsecond chip-wide).
+    // Compaction: wave ballot + mbcnt prefix inside the wave, a scan over the workgroup's waves, and
+    // ONE atomic per workgroup on the count word of the queue that owns the workgroup's blocks (a
+    // single word only sustains ~90 returning atomics per microsecond chip-wide; workgroups never
+    // straddle a queue boundary: those lie at multiples of 16 blocks).
     const unsigned long long m_valid = __builtin_amdgcn_ballot_w64(valid);
-    if (lane == 0) wave_count[wave] = (uint32_t)__builtin_popcountll(m_valid);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t sum = 0;
+    const uint32_t nq = (uint32_t)p.n_queues, sh = nq == 8u ? 3u : 0u;
+    const uint32_t n16 = ((p.total_rays >> 6) + 15u) >> 4;
+    const uint32_t g16 = (uint32_t)(((int64_t)blockIdx.x * GW) >> 4);  // this workgroup's group of 16 blocks
+    uint32_t qx = (uint32_t)(((uint64_t)g16 << sh) / n16);               // its queue: first guess, then exact
+    while (qx + 1u < nq && (queue_first_block(n16, qx + 1u, sh) >> 4) <= g16) ++qx;
+    while (qx > 0u && (queue_first_block(n16, qx, sh) >> 4) > g16) --qx;
+    uint32_t* const q_count = p.queue_head + qx * kQueueStride + 1;
+    const uint32_t q_base = queue_first_block(n16, qx, sh) << 6;
+    uint32_t my_base;
+    if constexpr (GW == 1) {
+        const uint32_t n = (uint32_t)__builtin_popcountll(m_valid);
+        uint32_t b = 0;
+        if (lane == 0 && n) b = atomicAdd(q_count, n);
+        my_base = q_base + (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+    } else {
+        if (lane == 0) wave_count[wave] = (uint32_t)__builtin_popcountll(m_valid);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0;
 #pragma unroll
-        for (int w = 0; w < kGenWaves; ++w) {
-            wave_base[w] = sum;
-            sum += wave_count[w];
+            for (int w = 0; w < GW; ++w) {
+                wave_base[w] = sum;
+                sum += wave_count[w];
+            }
+            const uint32_t base = q_base + (sum ? atomicAdd(q_count, sum) : 0u);
+#pragma unroll
+            for (int w = 0; w < GW; ++w) wave_base[w] += base;
         }
-        const uint32_t base = sum ? atomicAdd(p.ray_count_rw, sum) : 0u;
-#pragma unroll
-        for (int w = 0; w < kGenWaves; ++w) wave_base[w] += base;
+        __syncthreads();
+        my_base = wave_base[wave];
     }
-    __syncthreads();
     if (!valid) return;
     const uint32_t slot =
-        wave_base[wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_valid >> 32),
-                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m_valid, 0u));
+        my_base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_valid >> 32),
+                                            __builtin_amdgcn_mbcnt_lo((uint32_t)m_valid, 0u));
     uint32_t* rb = ray_slot(p.ray_buf_rw, kRayWords + p.ray_tail_words, slot);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -1501,13 +1540,12 @@ __global__ __launch_bounds__(kWave* kGenWaves) void raygen_kernel(const KParams 
 
 // Writes the per-launch frame table into device memory and resets the ray queue.
 // (Stream-ordered replacement for a pinned-memory H2D copy + memset.)
-__global__ void prepare_launch_kernel(FrameTable tbl, FrameDesc* frames, uint32_t* queue_head,
-                                      uint32_t* ray_count) {
+__global__ void prepare_launch_kernel(FrameTable tbl, FrameDesc* frames, uint32_t* queue_head) {
     const int i = threadIdx.x;
     if (i < tbl.n) frames[tbl.first + i] = tbl.f[i];
-    if (tbl.first == 0) {
-        if (i < 8) queue_head[i * kQueueStride] = 0u;
-        if (i == 0) *ray_count = 0u;
+    if (tbl.first == 0 && i < 8) {
+        queue_head[i * kQueueStride] = 0u;      // rays handed out
+        queue_head[i * kQueueStride + 1] = 0u;  // rays stored
     }
 }
 
@@ -1821,26 +1859,33 @@ hipError_t launch_fp(const KParams& p, int64_t want, int n_cus, int waves_overri
 
 hipError_t launch_prepare(const KParams& p, const FrameTable& tbl, hipStream_t stream) {
     hipLaunchKernelGGL(prepare_launch_kernel, dim3(1), dim3(64), 0, stream, tbl,
-                       const_cast<FrameDesc*>(p.frames), p.queue_head, p.ray_count_rw);
+                       const_cast<FrameDesc*>(p.frames), p.queue_head);
     return hipGetLastError();
 }
 
-hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_override,
+hipError_t launch_render(const KParams& p, int fp_mode, int n_cus, int waves_override, int gen_waves,
                          hipStream_t stream) {
     if (p.n_wave_blocks <= 0 || p.n_frames <= 0) return hipSuccess;
     const int64_t total_blocks = p.n_wave_blocks * p.n_frames;
-    {   // ray generation: kGenWaves wave blocks (8x8 pixels each) per workgroup
-        const dim3 ggrid((unsigned)((total_blocks + kGenWaves - 1) / kGenWaves));
-        const dim3 gblock(kWave * kGenWaves);
+    {   // ray generation: gen_waves wave blocks (8x8 pixels each) per workgroup
         const bool full = p.instrumented || p.render_depth || p.format == VR_FORMAT_SG ||
                           p.format == VR_FORMAT_ASG;
+#define VR_GEN(FMA_, FULL_, GW_)                                                                    \
+    hipLaunchKernelGGL((raygen_kernel<FMA_, FULL_, GW_>),                                           \
+                       dim3((unsigned)((total_blocks + GW_ - 1) / GW_)), dim3(kWave * GW_), 0, stream, p)
+#define VR_GEN_GW(FMA_, FULL_)                                                                      \
+    do {                                                                                            \
+        if (gen_waves >= 16) VR_GEN(FMA_, FULL_, 16);                                               \
+        else if (gen_waves >= 4) VR_GEN(FMA_, FULL_, 4);                                            \
+        else VR_GEN(FMA_, FULL_, 1);                                                                \
+    } while (0)
         if (fp_mode == VR_FP_FMA) {
-            if (full) hipLaunchKernelGGL((raygen_kernel<1, true>), ggrid, gblock, 0, stream, p);
-            else hipLaunchKernelGGL((raygen_kernel<1, false>), ggrid, gblock, 0, stream, p);
+            if (full) VR_GEN_GW(1, true); else VR_GEN_GW(1, false);
         } else {
-            if (full) hipLaunchKernelGGL((raygen_kernel<0, true>), ggrid, gblock, 0, stream, p);
-            else hipLaunchKernelGGL((raygen_kernel<0, false>), ggrid, gblock, 0, stream, p);
+            if (full) VR_GEN_GW(0, true); else VR_GEN_GW(0, false);
         }
+#undef VR_GEN_GW
+#undef VR_GEN
     }
     // persistent march grid: enough waves to fill the chip, but no more than one per
     // ~128 pixels so that small launches still rebalance through the ray queue
