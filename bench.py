@@ -398,7 +398,32 @@ def main():
                     g.copy_(o)
             return _Done()
 
-    gather_dist = HostStagedDist if share_gpu else dist
+    # The tile gather itself goes through the PRODUCT's collective (libvolrend_gather.so: one grouped
+    # ncclSend / ncclRecv to the root per launch -- what volrend_headless --gpus N ships);
+    # torch.distributed keeps the rendezvous, the barriers and the reduction of the timings.
+    gather_dist, gather_path = dist, None
+    if share_gpu:
+        gather_dist = HostStagedDist
+        gather_path = "REHEARSAL: gloo with host staging (RCCL refuses two ranks on one device)"
+    elif use_dist and not (args.mode == "replicas" and world > 1):
+        ok, err = 1, ""
+        try:
+            from volrend_amd import gather as vg
+            ids = [vg.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)  # the launcher's rendezvous carries the 128 bytes
+            gather_dist = vg.TileGather(ids[0], rank, world, dev_index)
+            gather_path = ("vr_gather_tiles (libvolrend_gather.so: grouped ncclSend / ncclRecv to the root, the "
+                           f"collective of volrend_headless --gpus N), RCCL {vg.version()}")
+        except Exception as e:  # noqa: BLE001 -- a SCALE run must not die here: fall back, and SAY so
+            ok, err = 0, repr(e)[:200]
+        agree = torch.tensor([ok], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree.item()) == 0:  # some rank could not join: every rank takes the same detour
+            gather_dist = dist
+            gather_path = f"torch.distributed.gather (FALLBACK: vr_gather did not initialise on every rank: {err})"
+            log(f"[bench r{rank}] {gather_path}")
 
     def barrier():
         if use_dist:
@@ -838,6 +863,7 @@ def main():
             }
         if use_dist:
             result["rccl"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                              "gather": gather_path,
                               "nccl_version": ".".join(map(str, torch.cuda.nccl.version()))
                               if not share_gpu else None,
                               "devices": torch.cuda.device_count()}

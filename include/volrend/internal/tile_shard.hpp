@@ -1,9 +1,11 @@
 // volrend::internal::TileShardRenderer -- one process drives N MI355X: every frame is cut into
 // interleaved screen tiles (VrFrame.tile_* / rank / world), rank r renders its tiles from its own
 // replica of the tree (vr_tree_clone: device to device) into a COMPACT buffer, the RGBA8 tiles
-// are gathered to the root GPU with RCCL (ncclCommInitAll, one grouped ncclSend / ncclRecv per
-// launch: every peer sends its share straight over its xGMI link to the root) and the root
-// de-interleaves the whole batch with one kernel (vr_assemble_tiles_batch).
+// are gathered to the root GPU with RCCL (libvolrend_gather, include/volrend_gather.h:
+// ncclCommInitAll, one grouped ncclSend / ncclRecv per launch: every peer sends its share straight
+// over its xGMI link to the root -- the same entry points bench.py --gpus N drives with one
+// process per rank) and the root de-interleaves the whole batch with one kernel
+// (vr_assemble_tiles_batch).
 //
 // The reference has no multi-GPU path; this is the native counterpart of
 // volrend_amd/dist.py + bench.py --gpus N for the kept volrend_headless CLI (--gpus / --tile).
@@ -66,7 +68,7 @@ class TileShardRenderer {
     std::vector<uint8_t*> compact_[2];  // per rank (peers; rank 0 only in the self-transfer mode)
     uint8_t* gather_[2] = {nullptr, nullptr};   // root: [n_ranks][max_batch][compact_bytes]
     uint8_t* frames_[2] = {nullptr, nullptr};   // root: [max_batch][H][W][4]
-    std::vector<void*> comm_;  // ncclComm_t per rank
+    std::vector<void*> comm_;  // vr_gather_t per rank
     std::string transport_, p2p_note_;
 };
 

@@ -174,3 +174,25 @@ def test_query_mode_rule_is_arithmetic():
     assert L.vr_query_mode_for(2, 9, 1 << 27) == desc            # node * 8 + slot words * 4 bytes >= 2^32
     assert L.vr_query_mode_for(2, 9, 1 << 40) == desc
     assert L.vr_query_mode_for(3, 3, 100) == desc and L.vr_query_mode_for(4, 2, 10) == desc
+
+
+def test_gather_library_exports_its_header():
+    """include/volrend_gather.h <-> libvolrend_gather.so <-> volrend_amd/gather.py: the tile
+    shard's RCCL collective behind a C ABI of its own (no compute calls here: symbols only)."""
+    from volrend_amd import gather
+    hdr = open(os.path.join(ROOT, "include", "volrend_gather.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    funcs = sorted(set(re.findall(r"^\s*(?:const char\*|int)\s+(vr_gather_\w+)\s*\(", hdr, flags=re.M)))
+    assert len(funcs) >= 11
+    if not os.path.exists(gather.LIB_PATH):
+        subprocess.check_call(["make", "-C", ROOT, "gather"], stdout=subprocess.DEVNULL)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", gather.LIB_PATH], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert sorted(s for s in exported if s.startswith("vr_")) == funcs
+    assert sorted(gather.PROTOTYPES) == funcs
+    L = gather.lib()  # resolves every symbol
+    assert L.vr_gather_version() > 20000 and gather.ID_BYTES == 128
+    # the library that renders stays free of RCCL (single-GPU users need none)
+    needed = subprocess.check_output(["readelf", "-d", _abi.LIB_PATH], text=True)
+    assert "rccl" not in needed
+    assert "rccl" in subprocess.check_output(["readelf", "-d", gather.LIB_PATH], text=True)

@@ -75,10 +75,26 @@ def test_bench_multirank_rehearsal(gpu, mode):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and "REHEARSAL" in d["data"]
     if mode == "tile":
+        assert "REHEARSAL" in d["rccl"]["gather"]
         assert d["scaling"] == "strong"
         assert d["config"]["sharded_frame_matches_single_gpu"] is True
     else:
         assert d["scaling"] == "weak" and "replicas" in d["config"]["parallelism"]
+
+
+def test_bench_one_rank_through_the_product_collective(gpu):
+    """VOLREND_FORCE_GATHER=1: the tile-shard path with ONE rank -- the frames travel through
+    libvolrend_gather.so (vr_gather_tiles: a grouped self ncclSend / ncclRecv, the collective
+    volrend_headless --gpus N ships) and the batch de-interleave, and must still equal the oracle."""
+    env = dict(os.environ, VOLREND_FORCE_GATHER="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C0", "--steps", "16",
+                        "--warmup", "8", "--batch", "4", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["parity"]["rgba8_equal"] is True
+    assert d["config"]["sharded_frame_matches_single_gpu"] is True
+    assert d["rccl"]["world_size"] == 1 and d["rccl"]["gather"].startswith("vr_gather_tiles"), d["rccl"]
 
 
 @pytest.mark.parametrize("mode", ["tile", "replicas"])
@@ -106,6 +122,7 @@ def test_bench_two_gpus_over_rccl(gpu, mode):
     if mode == "tile":
         assert d["config"]["sharded_frame_matches_single_gpu"] is True
         assert d["parity"]["rgba8_equal"] is True  # the GATHERED frames of the timed region vs the oracle
+        assert d["rccl"]["gather"].startswith("vr_gather_tiles"), d["rccl"]  # the product's collective, not a fallback
 
 
 def test_bench_plain_form_launches_itself(gpu):

@@ -2,7 +2,8 @@
 #include "volrend/internal/tile_shard.hpp"
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+
+#include "volrend_gather.h"
 
 #include <cstdlib>
 #include <stdexcept>
@@ -15,16 +16,15 @@ void hip_ok(hipError_t e, const char* what) {
     if (e != hipSuccess)
         throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
-void nccl_ok(ncclResult_t r, const char* what) {
-    if (r != ncclSuccess)
-        throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r));
+void gather_ok(int rc, const char* what) {  // libvolrend_gather: the shard's RCCL collective
+    if (rc != 0) throw std::runtime_error(std::string(what) + ": " + vr_gather_last_error());
 }
 void vr_ok(int rc, const char* what) {
     if (rc != VR_OK) throw std::runtime_error(std::string(what) + ": " + vr_last_error());
 }
 hipStream_t hs(void* s) { return static_cast<hipStream_t>(s); }
 hipEvent_t he(void* e) { return static_cast<hipEvent_t>(e); }
-ncclComm_t nc(void* c) { return static_cast<ncclComm_t>(c); }
+vr_gather_t gc(void* c) { return static_cast<vr_gather_t>(c); }
 
 }  // namespace
 
@@ -130,12 +130,10 @@ void TileShardRenderer::init(const N3Tree& tree, const TileShardConfig& cfg) {
         hip_ok(hipMalloc((void**)&frames_[s], frame_bytes() * max_batch_), "hipMalloc(frames)");
     }
     if (!share_) {
-        std::vector<ncclComm_t> comms(n_);
-        nccl_ok(ncclCommInitAll(comms.data(), n_, device_.data()), "ncclCommInitAll");
+        std::vector<vr_gather_t> comms(n_, nullptr);
+        gather_ok(vr_gather_init_all(n_, device_.data(), comms.data()), "vr_gather_init_all");
         for (auto c : comms) comm_.push_back(c);
-        int ver = 0;
-        ncclGetVersion(&ver);
-        transport_ = "RCCL " + std::to_string(ver) + ", " + std::to_string(n_) +
+        transport_ = "RCCL " + std::to_string(vr_gather_version()) + ", " + std::to_string(n_) +
                      (n_ == 1 ? " rank (self send/recv)" : " ranks, grouped send/recv to the root") +
                      (n_ > 1 ? ", " + p2p_note_ : "");
     } else {
@@ -155,7 +153,7 @@ void TileShardRenderer::release() {
         (void)hipSetDevice(device_[r]);
         (void)hipDeviceSynchronize();
     }
-    for (void* c : comm_) (void)ncclCommDestroy(nc(c));
+    for (void* c : comm_) (void)vr_gather_free(gc(c));
     comm_.clear();
     auto at = [](const auto& v, int r) { return r < (int)v.size() ? v[r] : nullptr; };
     for (int r = 0; r < n; ++r) {
@@ -223,14 +221,13 @@ void TileShardRenderer::render(int seq, const VrCamera* cams, int n, const VrRen
     }
     // 2. the tiles travel to the root: rank r's n shares land at gather + r * rank_stride
     if (!share_) {
-        nccl_ok(ncclGroupStart(), "ncclGroupStart");
-        for (int r = rccl_self_ ? 0 : 1; r < n_; ++r) {
-            nccl_ok(ncclSend(compact_[s][r], share * n, ncclUint8, 0, nc(comm_[r]),
-                             hs(comm_stream_[r])), "ncclSend");
-            nccl_ok(ncclRecv(gather_[s] + rank_stride * r, share * n, ncclUint8, r, nc(comm_[0]),
-                             hs(comm_stream_[0])), "ncclRecv");
-        }
-        nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+        // (the same entry point bench.py --gpus N drives, one rank per process there: include/volrend_gather.h)
+        gather_ok(vr_gather_group_begin(), "vr_gather_group_begin");
+        for (int r = 0; r < n_; ++r)
+            gather_ok(vr_gather_tiles(gc(comm_[r]), compact_[s][r], gather_[s], (int64_t)rank_stride,
+                                      (int64_t)(share * n), rccl_self_ ? 1 : 0, comm_stream_[r]),
+                      "vr_gather_tiles");
+        gather_ok(vr_gather_group_end(), "vr_gather_group_end");
     } else {
         hip_ok(hipSetDevice(device_[0]), "hipSetDevice");
         for (int r = 1; r < n_; ++r) {

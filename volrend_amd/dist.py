@@ -1,16 +1,21 @@
 """Multi-GPU frame pipeline: screen-tile shard + gather of the RGBA8 tiles to rank 0.
 
-One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI on the GPU
-box, "gloo" in the CPU tests).  The tree is replicated; every launch renders this rank's
-interleaved tiles of ``n`` frames into a COMPACT buffer (``VrFrame.layout``), ONE gather
-per launch moves the buffers to rank 0 -- each peer sends its ~1/world share straight to
-the root over its direct xGMI link -- and rank 0 de-interleaves them into frames.
-The gather of launch j overlaps the rendering of launch j+1 (two buffer sets); with a
-``stream_ctx`` the launches additionally alternate between streams, so that the ramp-up /
-tail of one launch overlaps its neighbour.
+One process per GPU.  The tree is replicated; every launch renders this rank's interleaved tiles
+of ``n`` frames into a COMPACT buffer (``VrFrame.layout``), ONE gather per launch moves the
+buffers to rank 0 -- each peer sends its ~1/world share straight to the root over its direct
+xGMI link -- and rank 0 de-interleaves them into frames.  The gather of launch j overlaps the
+rendering of launch j+1 (two buffer sets); with a ``stream_ctx`` the launches additionally
+alternate between streams, so that the ramp-up / tail of one launch overlaps its neighbour.
 
-The rendering and the assembly are callbacks, so the same pipeline drives the HIP
-library on GPUs and the CPU oracle in the gloo tests.
+This module is the PIPELINE (buffer sets, order of render / gather / assembly), not the
+collective.  The transport is whatever object is handed in as ``dist`` -- anything with
+``gather(tensor, gather_list, dst, async_op) -> work`` and ``work.wait()``:
+  * on GPUs: ``volrend_amd.gather.TileGather`` -- libvolrend_gather.so, the grouped
+    ncclSend / ncclRecv that ``volrend_headless --gpus N`` ships (bench.py --gpus N);
+  * in the CPU tests (tests/test_dist_gloo.py) and the shared-GPU rehearsal:
+    ``torch.distributed`` over gloo.
+The rendering and the assembly are callbacks, so the same pipeline drives the HIP library on
+GPUs and the CPU oracle in the gloo tests.
 """
 from __future__ import annotations
 
