@@ -38,8 +38,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 GATHER_LINES_PER_S = 53.5e9   # random 128-byte line requests the chip retires per second whatever the
                               # record size (tools/gather_bench.hip, profiles/r01_gather_ceiling.txt)
 N_SIMD, SIMD_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, peak shader clock (MI355X_MICROARCH.md)
-VALU_ISSUE_CYCLES = 4.0       # a wave64 vector instruction of this kernel's mix occupies its SIMD for 2.5-4
-                              # cycles (profiles/r04_valu_issue_cost.jsonl); 4 = the price SQ_ACTIVE_INST_VALU counts
+VALU_ISSUE_CYCLES = 4.0       # flat price of a wave64 vector instruction (what SQ_ACTIVE_INST_VALU counts); the chip's
+                              # own numbers are 2.5 / 4 / 7.6 cycles by class (profiles/r04_valu_issue_cost.jsonl):
+                              # roofline.model.t_issue_ms uses the class histogram of the kernel's ISA
+                              # (tools/isa_issue_model.py), t_issue_flat4_ms this flat price
 ROUND_FLOOR_US = 0.62         # a dependent march round of a lone wave on an otherwise idle SIMD: 1300-1500
                               # shader clocks (profiles/r04_tail_profile.jsonl, the last buckets of a one-frame launch)
 CACHE_DIR = os.environ.get("VOLREND_BENCH_CACHE", "/dev/shm/volrend_amd_cache")
@@ -168,6 +170,27 @@ def committed_traffic(config: str, fp: str, profiles_dir: str | None = None, hav
 
 
 committed_traffic.last_profile = None
+
+
+def issue_model(fp: str, basis_dim: int, blocked: bool, have_hash: str | None = None, profiles_dir: str | None = None):
+    """Vector-ALU cycles per instruction of the production flavour, by code region, from the newest
+    profiles/r*_isa_issue_model.json (tools/isa_issue_model.py: static class histogram of the ISA x the
+    measured per-class costs) whose kernel-source hash equals the sources this run was built from."""
+    import glob
+    if have_hash is None:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from measure_traffic import kernel_source_hash
+        have_hash = kernel_source_hash()
+    for path in sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"),
+                                              "r*_isa_issue_model.json")), reverse=True):
+        with open(path) as f:
+            d = json.load(f)
+        k = d.get("kernels", {}).get(f"{fp}/SH{basis_dim}/{'blocked' if blocked else 'xmajor'}")
+        if d.get("kernel_source_sha256") == have_hash and k:
+            return {"march_valu": k["march_round"]["valu"], "march_cpv": k["march_round"]["cycles_per_valu"],
+                    "rest_cpv": k["rest_of_kernel"]["cycles_per_valu"],
+                    "source": os.path.join("profiles", os.path.basename(path))}
+    return None
 
 
 def live_traffic(config: str, fp: str, frames_per_launch: int, tune: str):
@@ -842,9 +865,16 @@ def main():
         bounds = {}
         if traffic is not None:
             bounds["t_fabric_ms"] = traffic / 128.0 / GATHER_LINES_PER_S * 1e3
+        flat4, im = None, None
         if prof.get("valu_insts_per_frame"):
-            bounds["t_issue_ms"] = (prof["valu_insts_per_frame"] * fpl * VALU_ISSUE_CYCLES /
-                                    (N_SIMD * SIMD_HZ) * 1e3)
+            flat4 = prof["valu_insts_per_frame"] * fpl * VALU_ISSUE_CYCLES / (N_SIMD * SIMD_HZ) * 1e3
+            im = issue_model(args.fp, cfg["basis_dim"], bool(info.get("brick_blocked")))
+            if im:  # march rounds (instrumented flavour) x the round's static mix + the rest at the rest's mix
+                v_march = min(sched["march_rounds"] / n_distinct * im["march_valu"], prof["valu_insts_per_frame"])
+                cyc = v_march * im["march_cpv"] + (prof["valu_insts_per_frame"] - v_march) * im["rest_cpv"]
+                bounds["t_issue_ms"] = cyc * fpl / (N_SIMD * SIMD_HZ) * 1e3
+            else:
+                bounds["t_issue_ms"] = flat4
         if parity is not None and parity.get("longest_ray_samples"):
             bounds["t_chain_ms"] = parity["longest_ray_samples"] * ROUND_FLOOR_US * 1e-3
         if bounds:
@@ -854,9 +884,17 @@ def main():
                 "binding": binding,
                 "kernel_ms": round(kern_mean_s * 1e3, 5),
                 "frac_of_model": round(bounds[binding] / (kern_mean_s * 1e3), 4),
+                "t_issue_flat4_ms": None if flat4 is None else round(flat4, 5),
+                "frac_of_model_flat4": None if flat4 is None else round(
+                    max(flat4, *[v for k, v in bounds.items() if k != "t_issue_ms"]) / (kern_mean_s * 1e3), 4),
+                "t_issue_is": (f"class-weighted: {im['march_valu']} vector instructions per march round at "
+                               f"{im['march_cpv']} cycles, the rest at {im['rest_cpv']} ({im['source']}: ISA class "
+                               "histogram x 2.5 / 4 / 7.6 cycles, profiles/r04_valu_issue_cost.jsonl)") if im else
+                              "flat 4 cycles per vector instruction (no hash-verified ISA histogram of these sources)",
                 "what": "lower bounds of ONE launch: t_fabric = measured L2<->fabric lines / the chip's "
                         f"random-line rate ({GATHER_LINES_PER_S / 1e9:.1f} G lines/s, profiles/r01_gather_ceiling.txt); "
-                        f"t_issue = vector instructions (hash-verified PMC profile) x {VALU_ISSUE_CYCLES:.0f} cycles / "
+                        f"t_issue = vector instructions (hash-verified PMC profile) x their class-weighted cycles "
+                        f"(t_issue_is; flat {VALU_ISSUE_CYCLES:.0f} cycles: t_issue_flat4_ms) / "
                         f"({N_SIMD} SIMDs x {SIMD_HZ / 1e9:.1f} GHz); t_chain = samples of the longest ray of the "
                         f"checked frames x {ROUND_FLOOR_US} us (a dependent march round of a lone wave, "
                         "profiles/r05_tail_profile.jsonl); frac_of_model = the largest / the launch's duration",

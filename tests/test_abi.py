@@ -196,3 +196,21 @@ def test_gather_library_exports_its_header():
     needed = subprocess.check_output(["readelf", "-d", _abi.LIB_PATH], text=True)
     assert "rccl" not in needed
     assert "rccl" in subprocess.check_output(["readelf", "-d", gather.LIB_PATH], text=True)
+
+
+def test_product_sources_carry_no_experiment_hooks_and_the_patch_applies(tmp_path):
+    """Measurement builds (timing ablations, shader-clock timelines, knob overrides) are GENERATED:
+    volrend_amd/build.py copies csrc/ and applies tools/experiments/kernel_hooks.patch.  The product
+    sources themselves must not name a hook, the patch must apply to them as they are, and the
+    product build must refuse the hooks' flags."""
+    csrc = os.path.join(ROOT, "volrend_amd", "csrc")
+    for f in ("vr_kernels.hip", "vr_api.cpp", "vr_internal.h", "vr_device_math.h"):
+        text = open(os.path.join(csrc, f)).read()
+        assert not re.search(r"VR_EXP_|\bTL3?_[A-Z]|VR_ABLATE|VR_TIMELINE|vr_experiment_hooks", text), f
+    assert not os.path.exists(os.path.join(csrc, "vr_experiment_hooks.h"))
+    build.hooked_sources(str(tmp_path), dry_run=True)      # raises if a hunk does not apply
+    build.hooked_sources(str(tmp_path))
+    patched = open(os.path.join(str(tmp_path), "vr_kernels.hip")).read()
+    assert "VR_EXP_BRICK_WORD(" in patched and "TL3_ROUND(go)" in patched and "vr_experiment_hooks.h" in patched
+    with pytest.raises(ValueError):
+        build.build(extra_flags=["-DVR_ABLATE=4"])          # never into libvolrend_hip.so

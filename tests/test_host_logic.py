@@ -257,3 +257,33 @@ def test_bench_self_launch_command_and_relay(tmp_path, monkeypatch):
     assert rc == 3
     assert "RANK" not in seen["env"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert _json.loads(out.read_text().strip()) == {"metric": "x", "n_gpus": 2}
+
+
+def test_issue_model_is_hash_checked_and_class_weighted(tmp_path):
+    """roofline.model.t_issue prices vector instructions by class (2.5 / 4 / 7.6 cycles) from a static
+    histogram of the kernel's ISA (tools/isa_issue_model.py) -- but only while the histogram was made from
+    the sources the run was built from; and the classifier itself on a few instructions."""
+    import json as _json
+    import sys as _sys
+    import bench
+    _sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_issue_model as im
+    assert im.classify("\tv_fma_f32 v1, v2, v3, v4") == "cheap"
+    assert im.classify("\tv_mul_f32_e32 v1, 0x4b800000, v2") == "cheap"        # literal operand
+    assert im.classify("\tv_add_f32_e32 v1, s4, v2") == "full"                # SGPR operand
+    assert im.classify("\tv_med3_f32 v9, v2, 0, v54") == "full"
+    assert im.classify("\tv_lshl_or_b32 v10, v26, s34, v10") == "full"
+    assert im.classify("\tv_fma_mix_f32 v1, v2, v3, v4 op_sel_hi:[0,1,0]") == "full"
+    assert im.classify("\tv_rcp_f32_e32 v1, v2") == "trans"
+    assert im.classify("\ts_and_b64 s[0:1], s[2:3], vcc") is None and im.classify("\tds_read_b32 v1, v2") is None
+    h = im.histogram(["\tv_fma_f32 v1, v2, v3, v4", "\tv_cmp_lt_f32_e32 vcc, v1, v2", "\tv_exp_f32_e32 v1, v2",
+                      "\ts_mov_b32 s1, 0", "\tglobal_load_dword v1, v2, s[0:1]"])
+    assert (h["cheap"], h["full"], h["trans"], h["salu"], h["vmem"], h["valu"]) == (1, 1, 1, 1, 1, 3)
+    assert h["cycles_per_valu"] == round((2.5 + 4.0 + 7.6) / 3, 4)
+    rec = {"kernel_source_sha256": "abc", "kernels": {"strict/SH16/xmajor": {
+        "march_round": {"valu": 113, "cycles_per_valu": 3.5}, "rest_of_kernel": {"valu": 1300, "cycles_per_valu": 3.6}}}}
+    (tmp_path / "r09_isa_issue_model.json").write_text(_json.dumps(rec))
+    got = bench.issue_model("strict", 16, False, have_hash="abc", profiles_dir=str(tmp_path))
+    assert got["march_valu"] == 113 and got["march_cpv"] == 3.5 and got["rest_cpv"] == 3.6
+    assert bench.issue_model("strict", 16, False, have_hash="other", profiles_dir=str(tmp_path)) is None  # stale
+    assert bench.issue_model("strict", 16, True, have_hash="abc", profiles_dir=str(tmp_path)) is None     # other flavour

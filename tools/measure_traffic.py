@@ -56,7 +56,7 @@ GROUPS = {
     "sq4": "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_WAIT_INST_LDS",
     # TA_* and TD_* counters abort rocprofv3 on this pool (measured twice in round 1): not offered
 }
-SOURCES = ["volrend_amd/csrc/vr_kernels.hip", "volrend_amd/csrc/vr_device_math.h", "volrend_amd/csrc/vr_experiment_hooks.h",
+SOURCES = ["volrend_amd/csrc/vr_kernels.hip", "volrend_amd/csrc/vr_device_math.h",
            "volrend_amd/csrc/vr_internal.h", "volrend_amd/csrc/vr_api.cpp", "include/volrend_hip.h"]
 
 

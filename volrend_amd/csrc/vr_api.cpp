@@ -541,7 +541,7 @@ int basis_words_of(const VrTreeOpaque* t) {
 // and the lane that takes the ray evaluates the basis; everything else carries the basis values
 bool ray_carries_vdir(const VrTreeOpaque* t) {
     const int bw = basis_words_of(t);
-    return VR_RAY_VDIR && t->desc.format == VR_FORMAT_SH && bw > 3;
+    return t->desc.format == VR_FORMAT_SH && bw > 3;
 }
 int ray_tail_words_of(const VrTreeOpaque* t) { return ray_carries_vdir(t) ? 3 : basis_words_of(t); }
 
@@ -1205,7 +1205,7 @@ int vr_sched_stats(vr_tree_t t, uint64_t out[8], int reset) {
 }
 
 static uint64_t touch_granule(int which) {  // bytes one bit of the bitmap stands for
-    return which == 0 ? (1ull << VR_TOUCH_LEAF_SHIFT) : 128ull;
+    return which == 0 ? (1ull << vr::kTouchLeafShift) : 128ull;
 }
 static size_t touch_words(uint64_t array_bytes, int which) {  // one bit per 128-byte line
     const uint64_t g = touch_granule(which);

@@ -10,13 +10,8 @@ namespace vr {
 
 constexpr int kMaxBatch = 512;   // frames per launch (VR_MAX_BATCH)
 constexpr int kTableChunk = 48;  // frames per prepare_launch_kernel call (4 KB kernarg limit)
-#ifndef VR_TOUCH_LEAF_SHIFT
-#define VR_TOUCH_LEAF_SHIFT 7    // log2 of the bytes one bit of the records' distinct-line bitmap stands for
-                                 // (layout studies: 6 = one bit per 64-byte SH9 record slot)
-#endif
-#ifndef VR_RAY_VDIR
-#define VR_RAY_VDIR 1            // ray records of SH trees carry the view direction instead of the basis values
-#endif
+constexpr int kTouchLeafShift = 7;  // log2 of the bytes one bit of the records' distinct-line bitmap stands for
+                                    // (layout studies patch it: 6 = one bit per 64-byte SH9 record slot)
 
 // Per-frame part of a launch: pose and buffers.  Lives in device memory (one
 // small table per launch slot) because lanes of one wave may hold rays of

@@ -19,34 +19,13 @@ namespace vr {
 namespace {
 
 constexpr int kWave = 64;
-// Experiment hooks (timing ablations, shader-clock timelines): macros that expand to the plain
-// expression / nothing in the product build.
-#define VR_HOOKS_PART 1
-#include "vr_experiment_hooks.h"
-#undef VR_HOOKS_PART
-#ifndef VR_MIN_WAVES_PER_EU
-#define VR_MIN_WAVES_PER_EU 8  // cap on the per-flavour register bounds (experiments)
-#endif
-#ifndef VR_SH16_ROWS
-#define VR_SH16_ROWS 64  // SH16 items per shade round (56 fits 24 waves per CU into the LDS, but
-                         // measured slower: 0.275 against 0.265 ms per C1 frame)
-#endif
-#ifndef VR_SHADE_SCHED_BARRIER
-#define VR_SHADE_SCHED_BARRIER 0
-#endif
-#ifndef VR_SH16_WAVES
-#define VR_SH16_WAVES 5
-#endif
-#ifndef VR_SH25_WAVES
-#define VR_SH25_WAVES 4  // (5 = 96 VGPRs + 64 B of scratch with fenced shade math: measured 30 % slower)
-#endif
-#ifndef VR_SH9_WAVES
-#define VR_SH9_WAVES 7  // (72 VGPRs without scratch since the lane's ray id lives in LDS and the round counters in
-                        // scalar registers: round 5; C3 -1...-3 % against 6)
-#endif
-#ifndef VR_PACKED_EXP
-#define VR_PACKED_EXP 1       // the sigmoids of channels 0/1 share packed mul / fma / add instructions
-#endif
+// Register budget of the fused FAST flavours, waves per SIMD (each measured; EXPERIMENTS.md):
+constexpr int kSh16Waves = 5;   // 96 VGPRs (6 needs <= 80 and spills: 0.44 ms per C1 frame)
+constexpr int kSh25Waves = 4;   // 128 VGPRs (5 = 96 VGPRs + 64 B of scratch with fenced shade math: 30 % slower)
+constexpr int kSh9Waves = 7;    // 72 VGPRs without scratch since the lane's ray id lives in LDS and the round
+                                // counters in scalar registers (round 5; C3 -1...-3 % against 6)
+constexpr int kSh16Rows = 64;   // SH16 items per shade round (56 fits 24 waves per CU into the LDS, but measured
+                                // slower: 0.275 against 0.265 ms per C1 frame)
 // Guard against rays that never end (upstream would spin forever): KParams.max_iter march rounds
 // of a wave since its last retire / refill pass that retired a ray, default 2^22 (tuning key
 // `max_iter`, for tests).
@@ -190,7 +169,7 @@ enum { TOUCH_LEAVES = 0, TOUCH_NODES = 1, TOUCH_TOP = 2, TOUCH_BRICKS = 3 };
 __device__ __forceinline__ void touch(const KParams& p, int which, uint64_t off, uint32_t bytes) {
     uint32_t* bm = p.touch[which];
     if (!bm) return;
-    const int sh = which == TOUCH_LEAVES ? VR_TOUCH_LEAF_SHIFT : 7;
+    const int sh = which == TOUCH_LEAVES ? kTouchLeafShift : 7;
     const uint64_t l0 = off >> sh, l1 = (off + bytes - 1) >> sh;
     atomicOr(&bm[l0 >> 5], 1u << (l0 & 31u));
     if (l1 != l0) atomicOr(&bm[l1 >> 5], 1u << (l1 & 31u));
@@ -266,8 +245,7 @@ __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* 
     const uint32_t cell = ((((ux >> sh0) << g0) | (uy >> sh0)) << g0) | (uz >> sh0);
     if (cell != cur.cell) {
         // 32-bit byte offsets from a uniform base (top: <= 128 MB; bricks: < 4 GB, upload)
-        const uint2 e = VR_EXP_TOP_ENTRY(*reinterpret_cast<const uint2*>(
-            reinterpret_cast<const char*>(p.top) + (cell << 3)));
+        const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.top) + (cell << 3));
         if (COUNT) touch(p, TOUCH_TOP, (uint64_t)cell * 8u, 8u);
         cur.cell = cell;
         cur.e0 = e.x;
@@ -297,8 +275,7 @@ __device__ __forceinline__ uint32_t query_n2(const KParams& p, float* xyz, int* 
         }
         const uint32_t entry = (w << (3u * bl)) + sub;
         if (COUNT) touch(p, TOUCH_BRICKS, (uint64_t)entry * 4u, 4u);
-        w = VR_EXP_BRICK_WORD(*reinterpret_cast<const uint32_t*>(
-            reinterpret_cast<const char*>(p.bricks) + (entry << 2)));
+        w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.bricks) + (entry << 2));
         if (w & kLeafBit) {
             d = (int)(g0 + 1u + __builtin_amdgcn_ubfe(w, 29u, 2u));
             id = (id << 3) + __builtin_amdgcn_ubfe(w, 16u, 13u);  // (root + delta) * 8 + slot
@@ -385,7 +362,7 @@ __device__ __forceinline__ void load_record(const KParams& p, uint32_t leaf, Rec
         const uint4* v = reinterpret_cast<const uint4*>(base);
 #pragma unroll
         for (int j = 0; j < RecTraits<BASIS>::kDwords / 4; ++j) {
-            const uint4 q = VR_EXP_RECORD_CHUNK(v, j, leaf);
+            const uint4 q = v[j];
             r.w[4 * j + 0] = q.x;
             r.w[4 * j + 1] = q.y;
             r.w[4 * j + 2] = q.z;
@@ -462,8 +439,8 @@ template <int FMA, int BASIS, int LO, int HI, bool FENCE, typename GET>
 __device__ __forceinline__ void add_group(const char* row, GET&& get, float* acc) {
     float b[VR_MAX_BASIS];
     // FENCE keeps the scheduler from hoisting the next group's fetches over this group's
-    // arithmetic (lowest register use, but every group then waits for its own LDS round trip;
-    // experiments with tighter register budgets: VR_SHADE_SCHED_BARRIER)
+    // arithmetic (lowest register use, but every group then waits for its own LDS round trip: for
+    // flavours on a tighter register budget than they like -- none of the production ones)
     if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = LO; i <= HI; ++i) b[i] = get(i);
@@ -484,7 +461,7 @@ __device__ __forceinline__ void add_group(const char* row, GET&& get, float* acc
     }
 }
 
-template <int FMA, int BASIS, bool FENCE = (VR_SHADE_SCHED_BARRIER != 0), typename GET>
+template <int FMA, int BASIS, bool FENCE = false, typename GET>
 __device__ __forceinline__ void channel_sums(const char* row, GET&& get, float* acc) {
     static_assert(BASIS > 1, "SH / SG / ASG sizes only");
     {
@@ -826,9 +803,7 @@ __device__ __forceinline__ T* ray_slot(T* buf, int words_per_ray, uint32_t r) {
 __device__ __forceinline__ uint32_t ray_word(const uint32_t* slot, int k) { return slot[k * 64]; }
 constexpr int kRing = 128;   // capacity; at most 127 items are ever outstanding
 constexpr int kQueueStride = 16;  // words between queue heads (one 64-byte line each: head, count)
-#ifndef VR_STEAL_MIN
-#define VR_STEAL_MIN 8192  // rays a foreign queue must still hold to be worth a steal (or an eighth of its length)
-#endif
+constexpr uint32_t kStealMin = 8192;  // rays a foreign queue must still hold to be worth a steal (or an eighth of its length)
 
 // Ray queues.  The 8x8 pixel blocks of a launch (ray-id order: locate()) are cut into n_queues (1 or
 // 8) contiguous runs -- screen regions of the batch -- at multiples of 16 blocks; queue x owns the ray
@@ -849,7 +824,7 @@ __device__ __forceinline__ uint32_t queue_first_block(uint32_t n_groups16, uint3
 //     picked.  A single word sustains ~90 accesses per microsecond chip-wide (one queue for the
 //     whole chip: a one-frame launch takes 40 % longer, profiles/r03_steal_threshold.jsonl).
 //   * Waves steal from a queue only while it holds a good part of its rays (an eighth, at most
-//     VR_STEAL_MIN); the rest is left to the queue's own waves.  Stealing down to the last chunk
+//     kStealMin); the rest is left to the queue's own waves.  Stealing down to the last chunk
 //     -- round 2 -- had every wave of the chip visit every queue when they ran dry, all at
 //     about the same time, and scattered the last blocks of every screen region over all
 //     XCDs: a one-frame launch marched at a third of its rate for 50 us
@@ -872,7 +847,7 @@ __device__ __forceinline__ void grab_chunk(const KParams& p, int lane, uint32_t&
             const uint32_t seen = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (seen >= len) continue;
             if (a != 0u && gridDim.x >= nq &&
-                len - seen < ((len >> 3) < (uint32_t)VR_STEAL_MIN ? (len >> 3) : (uint32_t)VR_STEAL_MIN))
+                len - seen < ((len >> 3) < kStealMin ? (len >> 3) : kStealMin))
                 continue;  // not worth a steal
             uint32_t size = (len - seen) / (2u * waves_per_q);
             size = size < 64u ? 64u : (size > (uint32_t)p.chunk_max ? (uint32_t)p.chunk_max : size);
@@ -899,12 +874,12 @@ struct Stage {
     static constexpr int kVec = kEnabled ? RecTraits<BASIS>::kDwords / 4 : 1;  // V: 2, 4, 6, 10
     static constexpr int kRow = kVec * 16;                            // bytes
     static constexpr int kPerInstr = kWave / kVec;                    // records per DMA instruction
-    // Rows per pass: SH16 (96-byte rows) shades VR_SH16_ROWS = 64 items per round in one pass
+    // Rows per pass: SH16 (96-byte rows) shades kSh16Rows = 64 items per round in one pass
     // (6 KB of rows), SH25 (160-byte rows) 64 items in two passes of 32, the narrower formats 64
     // items in one pass.
     static constexpr int kPass = !kEnabled ? kWave
                                  : (kRow * kWave <= 5504 ? kWave
-                                    : (BASIS == BASIS_16 ? VR_SH16_ROWS : kWave / 2));  // rows per pass
+                                    : (BASIS == BASIS_16 ? kSh16Rows : kWave / 2));  // rows per pass
     static constexpr int kPasses = (BASIS == BASIS_25) ? 2 : 1;
     static constexpr int kShade = kPass * kPasses;                    // items per shade round
     static constexpr int kInstr = (kPass + kPerInstr - 1) / kPerInstr;
@@ -930,30 +905,28 @@ __device__ __forceinline__ void issue_records(const KParams& p, char* stage, con
         const int rin = k * ST::kPerInstr + lane / ST::kVec;  // record within the pass
         const int item = pass * ST::kPass + rin;
         if (lane < ST::kPerInstr * ST::kVec && rin < ST::kPass && item < n) {
-            const uint32_t leaf = VR_EXP_RECORD_LEAF(it_leaf[(ring_head + (uint32_t)item) & (RING - 1)]);
+            const uint32_t leaf = it_leaf[(ring_head + (uint32_t)item) & (RING - 1)];
             const char* src = reinterpret_cast<const char*>(p.leaves) +
                               (uint64_t)leaf * (uint32_t)(p.leaf_stride_h * 2) + (lane % ST::kVec) * 16;
             // (the LDS address is formed in address space 3: a generic-pointer detour between two
             // casts does not fold when `stage` is not the first LDS object of the kernel)
-            if (VR_EXP_RECORD_DMA)
-                __builtin_amdgcn_global_load_lds(
-                    (vr_gptr_t)src,
-                    (vr_lptr_t)((__attribute__((address_space(3))) char*)stage + k * ST::kPerInstr * ST::kRow),
-                    16, 0, NT ? 2 /* nt */ : 0);
+            __builtin_amdgcn_global_load_lds(
+                (vr_gptr_t)src,
+                (vr_lptr_t)((__attribute__((address_space(3))) char*)stage + k * ST::kPerInstr * ST::kRow),
+                16, 0, NT ? 2 /* nt */ : 0);
         }
     }
 }
 
 // Register budget of the fused FAST flavours (waves per SIMD), from their natural register use:
-// SH16 96 VGPRs -> VR_SH16_WAVES = 5 (20 waves per CU; 6 needs <= 80 and spills), SH9 <= 72 ->
-// VR_SH9_WAVES = 7, SH25 <= 128 -> 4 (it gathers its 25 basis values up front), the small
+// SH16 96 VGPRs -> kSh16Waves = 5 (20 waves per CU; 6 needs <= 80 and spills), SH9 <= 72 ->
+// kSh9Waves = 7, SH25 <= 128 -> 4 (it gathers its 25 basis values up front), the small
 // records 8.  The instrumented / lobe / generic flavours keep their wider state in registers at
 // 4 waves per SIMD (3 for SH25).  No render flavour uses scratch.
 template <int BASIS, int MODE>
 constexpr int min_waves_per_eu() {
     if (MODE != MODE_FAST) return BASIS == BASIS_25 ? 3 : 4;  // SH25 + counters needs > 128 VGPRs
-    const int want = BASIS == BASIS_25 ? VR_SH25_WAVES : BASIS == BASIS_16 ? VR_SH16_WAVES : BASIS == BASIS_9 ? VR_SH9_WAVES : 8;
-    return want < VR_MIN_WAVES_PER_EU ? want : VR_MIN_WAVES_PER_EU;
+    return BASIS == BASIS_25 ? kSh25Waves : BASIS == BASIS_16 ? kSh16Waves : BASIS == BASIS_9 ? kSh9Waves : 8;
 }
 // Waves one CU holds of a flavour: the register bound above or the LDS bound (512-byte granules).
 template <int BASIS, int MODE>
@@ -1014,14 +987,10 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
     uint32_t st_march_r = 0, st_march_l = 0, st_shade_r = 0, st_shade_l = 0, st_distinct = 0,
              st_fin_r = 0, st_fin_l = 0, st_iter = 0;
 
-    TL_DECL_FUSED();
-    TL3_DECL();
     // Colour evaluation of up to 64 queued items, one per lane, whoever owns them;
     // afterwards every owner adds the contributions of its own items, oldest first
     // (= the reference's accumulation order, rt_core.cuh:161).
     auto shade_chunk = [&](int n) {
-        TL_ADD(tl_march);
-        TL3_SHADE(n);
         __syncthreads();  // item pushes are visible
         if (COUNT) {
             st_shade_r++;
@@ -1077,26 +1046,20 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     else
                         issue_records<BASIS, false>(p, stage, it_leaf, ring_head, lane, n, pass);
                     __syncthreads();  // the DMAs have landed (vmcnt(0)) and are visible
-                    TL_ADD(tl_shade_load);
                     // (one pass: ALL lanes run the arithmetic -- an owner lane without an item
                     // of its own must stay active for the permutes; only `have` lanes keep results)
                     if (ST::kPasses == 1 || lane / ST::kPass == pass) {
                         const char* row = stage + (lane % ST::kPass) * ST::kRow;
                         float acc[3];
-                        channel_sums<FMA, BASIS, (VR_SHADE_SCHED_BARRIER != 0) || (BASIS == 25 && VR_SH25_WAVES >= 5)>(row, basis_get, acc);
+                        channel_sums<FMA, BASIS>(row, basis_get, acc);
                         // rt_core.cuh:161: weight / (1 + expf(-tmp)) per channel
-                        if constexpr (VR_PACKED_EXP) {
-                            const float2v e01 = vr_expf2((float2v){-acc[0], -acc[1]}) + splat2(1.f);
-                            r0 = weight / e01.x;
-                            r1 = weight / e01.y;
-                        } else {
-                            r0 = weight / (1.f + vr_expf(-acc[0]));
-                            r1 = weight / (1.f + vr_expf(-acc[1]));
-                        }
+                        // (the sigmoids of channels 0 / 1 share packed mul / fma / add instructions)
+                        const float2v e01 = vr_expf2((float2v){-acc[0], -acc[1]}) + splat2(1.f);
+                        r0 = weight / e01.x;
+                        r1 = weight / e01.y;
                         r2 = weight / (1.f + vr_expf(-acc[2]));
                     }
                     if (ST::kPasses > 1) __syncthreads();  // rows are free for the next pass
-                    TL_ADD(tl_shade_math);
                 }
             }
         } else {
@@ -1122,7 +1085,6 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
             res[2 * kWave + lane] = r2;
         }
         __syncthreads();  // contributions are visible
-        TL_ADD(tl_shade_math);
         const uint32_t head8 = ring_head & 0xFFu;
 #pragma unroll
         for (int d = 0; d < kOwnerQ; ++d) {
@@ -1143,12 +1105,10 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
             }
         }
         ring_head += (uint32_t)n;
-        TL_ADD(tl_shade_acc);
     };
 
     for (;;) {
         // ---- retire finished rays and hand their lanes new ones, in batches ----
-        TL_MARK();
         // A lane's ray is alive while t < tmax.  Nothing else says so: a ray that is cut short by
         // stop_thresh gets tmax = -1 (which finish_ray reads as "stopped"), a lane without a ray
         // has t = 0, tmax = -1.  (As loop-carried booleans the two cost the scalar unit -- shared
@@ -1200,7 +1160,6 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 hi = __builtin_amdgcn_readfirstlane(hi);
                 if (hi == lo) {
                     exhausted = true;
-                    TL_QUEUE_DRY();
                 } else {
                     chunk_next = lo;
                     chunk_end = hi;
@@ -1227,7 +1186,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     ray.tmax = u2f(ray_word(rs, 10));
                     ray.delta_scale = u2f(ray_word(rs, 11));
                     ray_ids[lane_id_now()] = r;
-                    if (HAS_BASIS && VR_EXP_FUSED_COLOUR) {
+                    if (HAS_BASIS) {
                         if (BASIS > 1 && p.ray_vdir) {
                             // rt_core.cuh:96-103: the basis of the ray's view direction (SH:
                             // lumisphere.hpp:38-81), zeroed outside basis_minmax -- evaluated
@@ -1272,7 +1231,6 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
         }
 
         // ---- march: lanes with a live ray and room for another outstanding item ----
-        TL_ADD(tl_refill);
         // Guard against rays that never end (not in the reference, which would spin): when the
         // wave has marched p.max_iter rounds since its last retire / refill pass that retired a ray
         // (progress_round above: with the default of 2^22 rounds the difference to "without a
@@ -1302,7 +1260,6 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                 st_march_r++;
                 st_march_l += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(go));
             }
-            TL3_ROUND(go);
             bool push = false;
             uint32_t leaf = 0;
             float weight = 0.f;
@@ -1340,10 +1297,8 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     weight = ray.light * (1.f - att);
                     if (COUNT && p.render_depth)  // (depth launches take the FULL flavour)
                         ray.out[0] = P::madd(weight, ray.t, ray.out[0]);
-                    else if (VR_EXP_FUSED_COLOUR)
-                        push = true;
                     else
-                        ray.out[1] += weight;
+                        push = true;
                     ray.light *= att;
                     stop = ray.light < p.stop_thresh;
                 }
@@ -1370,7 +1325,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
                     qsh -= 8u;
                 }
                 ring_tail += (uint32_t)__builtin_popcountll(m_push);
-                // (a loop: with rounds of fewer than 64 items -- VR_SH16_ROWS < 64 -- one round per
+                // (a loop: with rounds of fewer than 64 items -- kSh16Rows < 64 -- one round per
                 // march step would let the ring overflow)
                 while (ring_tail - ring_head >= (uint32_t)ST::kShade) shade_chunk(ST::kShade);
             }
@@ -1399,10 +1354,7 @@ __global__ __launch_bounds__(kWave, (min_waves_per_eu<BASIS, MODE>())) void rend
             const uint32_t waiting = ring_tail - ring_head;
             shade_chunk(waiting < (uint32_t)ST::kShade ? (int)waiting : ST::kShade);
         }
-        TL_ADD(tl_march);
     }
-    TL_DUMP_FUSED();
-    TL3_END();
     if (COUNT && p.sched_stats && lane == 0) {
         atomicAdd(&p.sched_stats[0], (unsigned long long)st_march_r);
         atomicAdd(&p.sched_stats[1], (unsigned long long)st_march_l);
@@ -1926,9 +1878,6 @@ hipError_t launch_probe(const KParams& p, const float probe[3], float* out_dev,
 
 int leaf_stride_halfs(int data_dim) {
     const int bytes = 2 * (data_dim - 1);
-#ifdef VR_EXP_SH25_STRIDE  // experiment (r05g): SH25 records on a 256-byte stride = two whole lines each
-    if (bytes == 150) return VR_EXP_SH25_STRIDE / 2;
-#endif
     int stride = 16;
     while (stride < bytes && stride < 128) stride *= 2;  // 16, 32, 64, 128: never straddles a line
     if (stride < bytes) stride = (bytes + 31) / 32 * 32;
@@ -1987,7 +1936,3 @@ hipError_t launch_decode_quant(const uint16_t* colors, const uint16_t* map, cons
 }
 
 }  // namespace vr
-
-#define VR_HOOKS_PART 2
-#include "vr_experiment_hooks.h"
-#undef VR_HOOKS_PART
