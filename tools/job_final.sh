@@ -2,7 +2,7 @@
 # ~8 GPU-minutes.  Everything lands in gpurun_out/<tag>/; the traffic JSONs are also copied to
 # profiles/ at once so that the bench lines taken afterwards can report them (source hash verified).
 set -u
-R=${1:-r05}
+R=${1:-r06}
 mkdir -p gpurun_out/$R
 export TMPDIR=/tmp
 O=gpurun_out/$R
@@ -18,6 +18,9 @@ cp $O/${R}_traffic_*.json profiles/
 # --- bench lines
 timeout 600 python bench.py > $O/${R}_final_bench.json 2> $O/final_bench.log; echo "bench rc=$?"
 timeout 400 python bench.py --steps 20 --warmup 5 > $O/${R}_final_bench_driverflags.json 2> $O/final_bench_driverflags.log
+# the same with the traffic measured by the run itself (two rocprofv3 --pmc passes of a child process after the
+# timed region: opt-in since round 6, the default line reports the committed hash-verified profile)
+timeout 400 python bench.py --steps 20 --warmup 5 --live-traffic 1 --no-cpu-baseline > $O/${R}_final_bench_driverflags_live_traffic.json 2> $O/final_bench_driverflags_live.log
 for c in C2 C3; do timeout 900 python bench.py --config $c --no-cpu-baseline > $O/${R}_bench_$c.json 2> $O/bench_$c.log; done
 timeout 300 python bench.py --fp fma --no-cpu-baseline > $O/${R}_bench_C1_fma.json 2>/dev/null
 timeout 300 python bench.py --readback --no-cpu-baseline > $O/${R}_bench_C1_readback.json 2>/dev/null
@@ -28,6 +31,12 @@ bash tools/lone_launch.sh $R > /dev/null 2>&1; cp gpurun_out/lone_$R.jsonl $O/${
 # --- small launches: anatomy (kernel trace), one / two alternating streams, the dependent round in an empty / full chip
 timeout 600 python tools/launch_anatomy.py --out $O/${R}_launch_anatomy.jsonl > $O/anatomy.log 2>&1
 timeout 600 python tools/stream_overlap.py --frames 1,2,4,8 --streams 1,2 --out $O/${R}_stream_overlap.jsonl > $O/overlap.log 2>&1
+for fs in "1 2" "2 2" "4 2"; do set -- $fs; timeout 300 python tools/overlap_trace.py --frames $1 --streams $2 --out $O/${R}_overlap_trace_final.jsonl > $O/trace_$1_$2.log 2>&1; done
+# the N > 1 bookkeeping of the driver's command with 8 ranks SHARING this one GPU (gloo, host-staged gather: a rehearsal of
+# the code path -- launcher, shards, pipeline, assembly, self-check, rank-0 line --, never a measurement)
+VOLREND_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 8 --steps 20 --warmup 5 --no-cpu-baseline > $O/${R}_rehearsal_8ranks_one_gpu.json 2> $O/rehearsal8.log; echo "rehearsal8 rc=$?"
+# C3: where the time goes (timing ablations in one process)
+timeout 900 python tools/quick_ab.py --config C3 --variants base,abl4,abl5,abl6 --tunes "" --frames 64 --reps 3 --rotate --out $O/${R}_C3_ablation_final.jsonl > $O/c3_abl.log 2>&1
 timeout 600 python tools/round_time_probe.py --out $O/${R}_round_time_probe.jsonl > $O/round_time.log 2>&1
 VOLREND_HIP_LIB=$PWD/volrend_amd/libvolrend_hip_tl3.so VR_TIMELINE=3 timeout 300 python tools/tail_profile.py --frames 1 --out $O/${R}_tail_profile_final.jsonl > $O/tail.log 2>&1
 # --- rocprofv3 kernel stats of the default and of the driver's command
