@@ -475,3 +475,52 @@ def test_raygen_workgroup_size_is_scheduling_only(torch_cuda, raygen_waves, xcd_
             frame = tiles.assemble_tiles(g, w, h, 16, 8, world)
             assert np.array_equal(frame, want[i]), f"shard world {world} pose {i}"
     t.free_device()
+
+
+def test_random_launch_shapes(torch_cuda):
+    """Seeded random LAUNCH shapes (what the ray queues and the ray generation see, not what a ray
+    computes): image size, poses per launch, tile shard (world, tile height), raygen workgroup size,
+    one or eight queues, camera distance (share of rays that miss the volume).  Every rank's COMPACT
+    buffer, assembled, must equal the oracle's frames.  VR_SHAPE_SEEDS=N widens the sweep."""
+    torch = torch_cuda
+    from volrend_amd import api, synth, tiles
+    rng0 = np.random.default_rng(4242)
+    trees = [common.small_scene(depth=d, basis_dim=b, seed=1400 + d) for d, b in ((4, 4), (5, 9), (6, 16))]
+    handles = [api.N3Tree.from_synth(t) for t in trees]
+    oracle_cache = {}
+    for seed in range(int(os.environ.get("VR_SHAPE_SEEDS", "10"))):
+        rng = np.random.default_rng(7000 + seed)
+        ti = int(rng.integers(len(trees)))
+        w, h = int(rng.integers(17, 200)), int(rng.integers(9, 140))
+        nf = int(rng.integers(1, 10))
+        world = int(rng.integers(1, 5))
+        tile_h = int(rng.choice([8, 16, 24]))
+        radius = float(rng.choice([3.0, 4.0, 6.5]))
+        f = float(rng.uniform(0.8, 2.2)) * w
+        gw = int(rng.choice([0, 1, 4, 16]))
+        xq = int(rng.integers(2))
+        poses = synth.make_poses(16, radius=radius)
+        trs = [synth.c2w_to_transform(poses[int(rng.integers(16))]) for _ in range(nf)]
+        t = handles[ti]
+        t.set_tuning(raygen_waves=gw, xcd_queues=xq)
+        cam = api.Camera(w, h, f, f)
+        tile_w = (w + 7) // 8 * 8
+        parts = []
+        for rank in range(world):
+            shard = api.TileShard(tile_w, tile_h, rank, world, compact=True)
+            nb = api.compact_bytes(w, h, shard)
+            buf = torch.zeros((nf, nb), dtype=torch.uint8, device="cuda")
+            api.launch_renderer_batch(t, cam, trs, api.RenderOptions(), [buf[i] for i in range(nf)], None, True,
+                                      shard=shard)
+            parts.append(buf)
+        torch.cuda.synchronize()
+        assert t.status() == 0
+        parts = [p.cpu().numpy() for p in parts]
+        what = f"seed {seed}: tree {ti} {w}x{h} x{nf} world {world} tile_h {tile_h} raygen_waves {gw} queues {8 if xq else 1} r {radius}"
+        for i, tr in enumerate(trs):
+            want = common.oracle_frame(trees[ti], tr, w, h, f)[0]
+            g = np.stack([parts[r][i].reshape(-1, 4) for r in range(world)])
+            got = tiles.assemble_tiles(g, w, h, tile_w, tile_h, world)
+            assert np.array_equal(got, want), what + f" pose {i}"
+    for t in handles:
+        t.free_device()
