@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Longest-first block order from a temporal cost map, simulated (tools/drain_sim.py wave-level model on the real
+per-ray sample counts of C1): blocks of a launch ordered by the longest ray of the same block in the previous launch,
+by its true longest ray, and with the map dilated.  Result: profiles/r06_lpt_sim.jsonl -- and the chip's answer to the
+same question, which is a different one: profiles/r06_cost_order.jsonl (EXPERIMENTS.md round 6).
+    python tools/lpt_sim.py > profiles/r06_lpt_sim.jsonl     (CPU, ~10 min)"""
 import sys, json, numpy as np
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
 import drain_sim as ds
