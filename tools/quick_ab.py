@@ -58,6 +58,15 @@ def main():
         _abi.LIB_PATH = (os.path.join(ROOT, "volrend_amd", "libvolrend_hip.so") if v == "base" else
                          os.path.join(ROOT, "volrend_amd", f"libvolrend_hip_{v}.so"))
         tree = api.N3Tree.from_synth(stree)
+        # the first measurements of a process run while the GPU's clocks still ramp up (an MI355X out of idle
+        # needs >= 30 ms of work, profiles/r04_lone_launch_probe.jsonl): ~250 ms of untimed frames first, or
+        # whatever stands first in --tunes looks 3-5 % slower than it is (profiles/r06_frame_group.jsonl)
+        npre = min(nmax, 64)
+        pre = api.PreparedBatch(tree, cam, [transforms[(100 + i) % 200] for i in range(npre)], opts,
+                                [imgs[i] for i in range(npre)], True, fp_mode=fp_mode)
+        for _ in range(max(1, 1024 // npre)):
+            pre.launch(stream)
+        torch.cuda.synchronize()
         for tune in args.tunes.split(";"):
             if tune:
                 tree.set_tuning(**{k: int(x) for k, x in (kv.split("=") for kv in tune.split(","))})
